@@ -1,0 +1,200 @@
+"""CPU parity oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may
+import this package.  It is never the thing measured or shipped; the product
+path (mcmc_amd) does not import it and fails loudly without its HIP library.
+
+`oracle.lib()` loads oracle/_build/libsurf96_oracle.so (built by
+`make -C oracle`, which `__graft_entry__.build()` runs) and exposes numpy-level
+wrappers around the C restatement in surf96_oracle.c.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libsurf96_oracle.so")
+_lib = None
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_lp = ctypes.POINTER(ctypes.c_int64)
+_llp = ctypes.POINTER(ctypes.c_longlong)
+_bp = ctypes.POINTER(ctypes.c_uint8)
+c_int, c_double = ctypes.c_int, ctypes.c_double
+
+STATUS_OK, STATUS_BOUNDS, STATUS_PHYSICS, STATUS_NOROOT, STATUS_ZERODIV = 0, 1, 2, 3, 4
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        L.orc_secular.restype = c_double
+        L.orc_secular.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_double, c_double]
+        L.orc_dispersion.argtypes = [_dp, _dp, _dp, _dp, c_int, _dp, c_int, c_int, c_int, c_int,
+                                     c_double, c_double, _dp, _llp]
+        L.orc_layer_table.restype = None
+        L.orc_layer_table.argtypes = [_dp, c_int, c_double, _dp, _dp, _dp, _dp]
+        L.orc_forward.argtypes = [_dp, c_int, c_double, _dp, c_int, c_int, c_int, c_int, c_double,
+                                  c_double, _dp, _llp]
+        L.orc_forward_batch.argtypes = [_dp, c_int, c_int, c_double, _dp, c_int, c_int, c_int,
+                                        c_int, c_double, c_double, _dp, _ip, _llp, c_int]
+        L.orc_npsum.restype = c_double
+        L.orc_npsum.argtypes = [_dp, ctypes.c_long]
+        L.orc_loglik.restype = c_double
+        L.orc_loglik.argtypes = [_dp, _dp, c_int, c_int, _dp, c_int, _dp, c_int]
+        L.orc_sort_layers.restype = None
+        L.orc_sort_layers.argtypes = [_dp, c_int]
+        L.orc_mh_step.argtypes = [
+            _dp, _dp, _dp, _dp, _dp, _dp, _dp, _lp, _lp, _dp, _dp, c_double, c_int, c_int,
+            c_double, _dp, c_int, _dp, c_int, _dp, c_int, _dp, c_int, c_int, c_int, c_int,
+            c_double, c_double, c_int, c_int, _ip, _dp, _dp, _bp, _ip, _llp]
+        L.orc_cov_accumulate.restype = None
+        L.orc_cov_accumulate.argtypes = [_dp, _dp, _dp, _lp, _dp, c_int, c_int]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def layer_table(m, n_layers, vpvs):
+    m = _f64(m)
+    L = n_layers + 1
+    d, a, b, rho = (np.zeros(L) for _ in range(4))
+    lib().orc_layer_table(_d(m), n_layers, vpvs, _d(d), _d(a), _d(b), _d(rho))
+    return d, a, b, rho
+
+
+def secular(d, a, b, rho, period, c, wave=0):
+    d, a, b, rho = map(_f64, (d, a, b, rho))
+    return lib().orc_secular(_d(d), _d(a), _d(b), _d(rho), len(d), wave, float(period), float(c))
+
+
+def dispersion(d, a, b, rho, periods, wave=0, mode=0, itype=0, dc=0.005, dt=0.025):
+    d, a, b, rho, periods = map(_f64, (d, a, b, rho, periods))
+    vel = np.zeros(len(periods))
+    ne = ctypes.c_longlong(0)
+    st = lib().orc_dispersion(_d(d), _d(a), _d(b), _d(rho), len(d), _d(periods), len(periods),
+                              wave, mode, itype, dc, dt, _d(vel), ctypes.byref(ne))
+    return st, vel, ne.value
+
+
+def forward(m, n_layers, vpvs, periods, wave=0, mode=0, itype=0, dc=0.005, dt=0.025):
+    """forward_model(periods, model_params): returns (status, velocity[P], n_evals)."""
+    m, periods = _f64(m), _f64(periods)
+    vel = np.zeros(len(periods))
+    ne = ctypes.c_longlong(0)
+    st = lib().orc_forward(_d(m), n_layers, vpvs, _d(periods), len(periods), wave, mode, itype,
+                           dc, dt, _d(vel), ctypes.byref(ne))
+    return st, vel, ne.value
+
+
+def forward_batch(params, n_layers, vpvs, periods, wave=0, mode=0, itype=0, dc=0.005, dt=0.025,
+                  nthreads=1):
+    params, periods = _f64(params), _f64(periods)
+    B, P = params.shape[0], len(periods)
+    vel = np.zeros((B, P))
+    status = np.zeros(B, dtype=np.int32)
+    ne = ctypes.c_longlong(0)
+    lib().orc_forward_batch(_d(params), B, n_layers, vpvs, _d(periods), P, wave, mode, itype, dc,
+                            dt, _d(vel), status.ctypes.data_as(_ip), ctypes.byref(ne), nthreads)
+    return status, vel, ne.value
+
+
+def npsum(a):
+    a = _f64(a)
+    return lib().orc_npsum(_d(a), len(a))
+
+
+def noise_arrays(noise_dist, noise_params, P):
+    """(code, a, b): the two per-period / scalar arrays orc_loglik takes.
+
+    normal: a = std (scalar or [P]).  asym-laplace: a = lambd_scale*lambd clipped at
+    lambd_max (model.py:438-440), b = kappa.
+    """
+    if noise_dist == "normal":
+        a = np.atleast_1d(_f64(noise_params["std"]))
+        return 0, a, np.ones(1)
+    if noise_dist == "asym-laplace":
+        lam = noise_params["lambd_scale"] * _f64(noise_params["lambd"])
+        lam = np.atleast_1d(lam).copy()
+        if "lambd_max" in noise_params:
+            lam[lam >= noise_params["lambd_max"]] = noise_params["lambd_max"]
+        kap = np.atleast_1d(_f64(noise_params["kappa"]))
+        return 1, lam, kap
+    raise ValueError(noise_dist)
+
+
+def loglik(obs, pred, noise_dist, noise_params):
+    obs, pred = _f64(obs), _f64(pred)
+    code, a, b = noise_arrays(noise_dist, noise_params, len(obs))
+    return lib().orc_loglik(_d(obs), _d(pred), len(obs), code, _d(a), len(a), _d(b), len(b))
+
+
+def sort_layers(m, n_layers):
+    m = _f64(m).copy()
+    lib().orc_sort_layers(_d(m), n_layers)
+    return m
+
+
+class ChainState:
+    """Batch of B chains in the layout orc_mh_step takes."""
+
+    def __init__(self, m, logL, pred, width, bounds):
+        self.m = _f64(m).copy()
+        B, NP = self.m.shape
+        self.B, self.NP = B, NP
+        self.logL = _f64(logL).copy()
+        self.pred = _f64(pred).copy()
+        self.params_prev = np.zeros((B, NP))
+        self.width = np.broadcast_to(_f64(width), (B, NP)).copy()
+        self.rot = np.broadcast_to(np.eye(NP), (B, NP, NP)).copy()
+        self.cov_sum = np.zeros((B, NP, NP))
+        self.n_cov = np.zeros(B, dtype=np.int64)
+        self.counters = np.zeros((B, 5), dtype=np.int64)
+        self.bounds = _f64(bounds).copy()
+
+
+def mh_step(state, idx, cauchy, u_acc, n_layers, vpvs, periods, obs, noise_dist, noise_params,
+            beta=None, T=1.0, wave=0, mode=0, itype=0, dc=0.005, dt=0.025, rotate=0,
+            sample_prior=False):
+    periods, obs = _f64(periods), _f64(obs)
+    P = len(periods)
+    code, na, nb = noise_arrays(noise_dist, noise_params, P)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    cauchy, u_acc = _f64(cauchy), _f64(u_acc)
+    beta = None if beta is None else _f64(beta)
+    accepted = np.zeros(state.B, dtype=np.uint8)
+    status = np.zeros(state.B, dtype=np.int32)
+    ne = ctypes.c_longlong(0)
+    rc = lib().orc_mh_step(
+        _d(state.m), _d(state.logL), _d(state.pred), _d(state.params_prev), _d(state.width),
+        _d(state.rot), _d(state.cov_sum), state.n_cov.ctypes.data_as(_lp),
+        state.counters.ctypes.data_as(_lp), _d(state.bounds), _d(beta), float(T), state.B,
+        n_layers, vpvs, _d(periods), P, _d(obs), code, _d(na), len(na), _d(nb), len(nb), wave,
+        mode, itype, dc, dt, int(rotate), int(bool(sample_prior)), idx.ctypes.data_as(_ip),
+        _d(cauchy), _d(u_acc), accepted.ctypes.data_as(_bp), status.ctypes.data_as(_ip),
+        ctypes.byref(ne))
+    assert rc == 0, rc
+    return accepted, status, ne.value
+
+
+def cov_accumulate(state):
+    """update_covariance_matrix alone (model.py:263-282)."""
+    lib().orc_cov_accumulate(_d(state.m), _d(state.params_prev), _d(state.cov_sum),
+                             state.n_cov.ctypes.data_as(_lp), _d(state.bounds), state.B, state.NP)
