@@ -1,0 +1,173 @@
+/*
+ * mcmc_amd.h -- C ABI of the MI355X (gfx950) dispersion-inversion hot path.
+ *
+ * The reference (jamiebyer/mcmc) is pure Python and defines no FFI; its seam
+ * for this path is a pair of Python methods.  Each entry point below names the
+ * reference code it replaces (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - every pointer marked "device" is caller-owned HBM (for example
+ *     torch.Tensor.data_ptr()); the library allocates nothing and never frees;
+ *   - all arrays are dense row-major, float64 unless stated;
+ *   - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL
+ *     is the default stream) and return 0 or a negative MHD_E* code;
+ *     mhd_last_error() gives the text of the last failure on this thread;
+ *   - per-chain outcome codes (`status`) map onto the reference's counters:
+ *       MHD_ST_OK       proposal evaluated
+ *       MHD_ST_BOUNDS   n_bounds_err   (src/inversion/model.py:110-117)
+ *       MHD_ST_PHYSICS  n_physics_err  (src/inversion/model.py:120-127)
+ *       MHD_ST_NOROOT   n_fm_err, disba DispersionError (src/inversion/model.py:134-140)
+ *       MHD_ST_ZERODIV  n_fm_err, ZeroDivisionError      (src/inversion/model.py:134-140)
+ */
+#ifndef MCMC_AMD_H
+#define MCMC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHD_ABI_VERSION 1
+
+#define MHD_OK 0
+#define MHD_EINVAL (-22) /* bad argument (size beyond a compiled limit, NULL pointer) */
+#define MHD_EHIP (-5)    /* a HIP runtime call failed */
+
+#define MHD_ST_OK 0
+#define MHD_ST_BOUNDS 1
+#define MHD_ST_PHYSICS 2
+#define MHD_ST_NOROOT 3
+#define MHD_ST_ZERODIV 4
+
+#define MHD_RAYLEIGH 0
+#define MHD_LOVE 1
+#define MHD_PHASE 0
+#define MHD_GROUP 1
+#define MHD_NORMAL 0
+#define MHD_ASYM_LAPLACE 1
+
+/* compiled limits */
+#define MHD_MAX_LAYERS 15   /* finite layers; rows = n_layers + 1 <= 16 */
+#define MHD_MAX_PERIODS 128
+
+/* rotate flags of mhd_mh_steps */
+#define MHD_ROT_ACCUMULATE 1 /* update_covariance_matrix before proposing  */
+#define MHD_ROT_FRAME 2      /* propose in the rotated (principal-component) frame */
+
+/*
+ * Static description of one inversion problem: the parameterisation of
+ * DispersionCurveParams (src/inversion/model_params.py:25-55) and the data /
+ * noise model that Model.get_likelihood reads (src/inversion/model.py:420-447).
+ */
+typedef struct mhd_problem {
+    int32_t n_layers;   /* finite layers; NP = 2*n_layers+1 parameters =
+                           [n_layers interface depths, n_layers+1 vs]   */
+    int32_t n_periods;  /* P */
+    int32_t wave;       /* MHD_RAYLEIGH | MHD_LOVE  (disba wave=)        */
+    int32_t mode;       /* 0 = fundamental          (disba mode=)        */
+    int32_t itype;      /* MHD_PHASE | MHD_GROUP                         */
+    int32_t noise_dist; /* MHD_NORMAL | MHD_ASYM_LAPLACE                 */
+    int32_t n_noise_a;  /* 1 or P: length of noise_a                     */
+    int32_t n_noise_b;  /* 1 or P: length of noise_b                     */
+    double vpvs;        /* vp = vs * vpvs   (model_params.py:95-97)      */
+    double dc;          /* bracketing step, disba default 0.005 km/s     */
+    double dt;          /* group-velocity period offset, disba 0.025     */
+    const double *periods; /* device [P], ascending (src/main.py:29)     */
+    const double *obs;     /* device [P] data_obs; may be NULL for forward-only calls */
+    const double *noise_a; /* device: std (normal) | lambd_scale*lambd clipped at
+                              lambd_max (asym-laplace, model.py:438-440)  */
+    const double *noise_b; /* device: kappa (asym-laplace) or NULL        */
+    const double *bounds;  /* device [NP,3] = lo, hi, hi-lo
+                              (model_params.py:104-126); NULL for forward-only */
+} mhd_problem_t;
+
+/*
+ * Mutable state of B chains: the attributes Model.perturb_params mutates
+ * (src/inversion/model.py:244-256, :263-282) for every chain at once.
+ */
+typedef struct mhd_chains {
+    double *m;           /* device [B,NP] model_params.model_params           */
+    double *logL;        /* device [B]                                        */
+    double *pred;        /* device [B,P] data_pred                            */
+    double *params_prev; /* device [B,NP] normalised previous accepted params */
+    double *width;       /* device [B,NP] proposal_width                      */
+    double *rot;         /* device [B,NP,NP] rotation_matrix, or NULL         */
+    double *cov_sum;     /* device [B,NP,NP] cov_mat_sum, or NULL             */
+    int64_t *n_cov;      /* device [B], or NULL                               */
+    int64_t *counters;   /* device [B,5]: n_acc, n_rej, n_bounds_err,
+                            n_physics_err, n_fm_err                           */
+    int64_t *counters_ind; /* device [B,NP,5] per-parameter counters
+                            (individual_acceptance, model.py:46-58), or NULL  */
+    const double *beta;  /* device [B] tempering exponent, or NULL for 1      */
+} mhd_chains_t;
+
+int mhd_abi_version(void);
+const char *mhd_last_error(void);
+
+/*
+ * Secular (period-equation) function values, for diagnostics and parity gates:
+ * delta[i] = Delta(c[i]) of chain chain[i] at period index period[i].
+ * Replaces nothing the reference calls directly; it is disba's dltar4 / dltar1
+ * reached through src/inversion/model_params.py:201-206.
+ */
+int mhd_secular_batch(const mhd_problem_t *prob, const double *params /* device [B,NP] */,
+                      int32_t B, const int32_t *chain /* device [N] */,
+                      const int32_t *period /* device [N] */, const double *c /* device [N] */,
+                      int32_t N, double *delta /* device [N] */, void *stream);
+
+/*
+ * DispersionCurveParams.forward_model for B parameter vectors
+ * (src/inversion/model_params.py:178-209; the disba call at :201-206).
+ * vel[b,:] is the phase (or group) velocity curve, status[b] is MHD_ST_OK or
+ * the code of the exception the reference would raise.  n_evals, if not NULL,
+ * is device uint64[2] and is INCREMENTED by {secular evaluations the
+ * sequential disba algorithm performs, evaluations actually executed}.
+ */
+int mhd_forward_batch(const mhd_problem_t *prob, const double *params /* device [B,NP] */,
+                      int32_t B, double *vel /* device [B,P] */,
+                      int32_t *status /* device [B] */, uint64_t *n_evals, void *stream);
+
+/*
+ * Model.get_likelihood for B predicted curves (src/inversion/model.py:420-447);
+ * sums in numpy's float64 add.reduce order.
+ */
+int mhd_loglik_batch(const mhd_problem_t *prob, const double *pred /* device [B,P] */,
+                     int32_t B, double *logL /* device [B] */, void *stream);
+
+/*
+ * n_steps consecutive Model.perturb_params calls for each of B chains
+ * (src/inversion/model.py:146-257 with validate_params :107-144,
+ * acceptance_criteria :449-467 and the counters of :469-532), the chain x thin
+ * nest of Inversion.random_walk (src/inversion/inversion.py:399-412).
+ *
+ * Draws are host-supplied, one triple per (step, chain):
+ *   idx[s,b]    the perturbed parameter      (np.random.randint, model.py:196)
+ *   cauchy[s,b] tan(pi*(u-1/2))              (model.py:210-212)
+ *   u_acc[s,b]  the accept uniform           (model.py:466)
+ * accept iff u_acc <= exp(beta*(logL_new-logL)/T).
+ * rotate is a mask of MHD_ROT_*.  sample_prior != 0 skips the forward model
+ * and uses logL_new = 1 (model.py:234-236).
+ * Optional outputs (NULL to skip): accepted[S,B] (uint8), status[S,B],
+ * hist_m[S/hist_every,B,NP], hist_logL[S/hist_every,B] written after every
+ * hist_every-th step.  n_evals as in mhd_forward_batch.
+ */
+int mhd_mh_steps(const mhd_problem_t *prob, const mhd_chains_t *chains, int32_t B,
+                 int32_t n_steps, const int32_t *idx /* device [S,B] */,
+                 const double *cauchy /* device [S,B] */, const double *u_acc /* device [S,B] */,
+                 double T, int32_t rotate, int32_t sample_prior,
+                 uint8_t *accepted, int32_t *status, int32_t hist_every, double *hist_m,
+                 double *hist_logL, uint64_t *n_evals, void *stream);
+
+/*
+ * Model.update_covariance_matrix alone (src/inversion/model.py:263-282), used on
+ * the steps where the reference refreshes the rotation matrix between the
+ * covariance update and the proposal (model.py:183-193).
+ */
+int mhd_cov_accumulate(const mhd_problem_t *prob, const mhd_chains_t *chains, int32_t B,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCMC_AMD_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of the C ABI in include/mcmc_amd.h.
+
+The shared library is built in-tree by `python -m mcmc_amd.build` (hipcc,
+--offload-arch=gfx950).  There is no CPU fallback: if the library is missing
+or cannot be loaded this module raises, and every product entry point fails.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmcmc_amd.so")
+
+c_int32, c_double, c_void_p = ctypes.c_int32, ctypes.c_double, ctypes.c_void_p
+
+ST_OK, ST_BOUNDS, ST_PHYSICS, ST_NOROOT, ST_ZERODIV = 0, 1, 2, 3, 4
+RAYLEIGH, LOVE = 0, 1
+PHASE, GROUP = 0, 1
+NORMAL, ASYM_LAPLACE = 0, 1
+ROT_ACCUMULATE, ROT_FRAME = 1, 2
+MAX_LAYERS, MAX_PERIODS = 15, 128
+ABI_VERSION = 1
+
+EXPORTS = (
+    "mhd_abi_version",
+    "mhd_last_error",
+    "mhd_secular_batch",
+    "mhd_forward_batch",
+    "mhd_loglik_batch",
+    "mhd_mh_steps",
+    "mhd_cov_accumulate",
+)
+
+
+class Problem(ctypes.Structure):
+    """struct mhd_problem"""
+    _fields_ = [
+        ("n_layers", c_int32), ("n_periods", c_int32), ("wave", c_int32), ("mode", c_int32),
+        ("itype", c_int32), ("noise_dist", c_int32), ("n_noise_a", c_int32),
+        ("n_noise_b", c_int32), ("vpvs", c_double), ("dc", c_double), ("dt", c_double),
+        ("periods", c_void_p), ("obs", c_void_p), ("noise_a", c_void_p), ("noise_b", c_void_p),
+        ("bounds", c_void_p),
+    ]
+
+
+class Chains(ctypes.Structure):
+    """struct mhd_chains"""
+    _fields_ = [
+        ("m", c_void_p), ("logL", c_void_p), ("pred", c_void_p), ("params_prev", c_void_p),
+        ("width", c_void_p), ("rot", c_void_p), ("cov_sum", c_void_p), ("n_cov", c_void_p),
+        ("counters", c_void_p), ("counters_ind", c_void_p), ("beta", c_void_p),
+    ]
+
+
+class MhdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libmcmc_amd.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MhdError(
+            f"{LIB_PATH} not found: build the HIP library first (python -m mcmc_amd.build). "
+            "There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    pp, cp = ctypes.POINTER(Problem), ctypes.POINTER(Chains)
+    L.mhd_abi_version.restype = ctypes.c_int
+    L.mhd_abi_version.argtypes = []
+    L.mhd_last_error.restype = ctypes.c_char_p
+    L.mhd_last_error.argtypes = []
+    L.mhd_secular_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
+                                    c_void_p, c_void_p]
+    L.mhd_forward_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.mhd_loglik_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p]
+    L.mhd_mh_steps.argtypes = [pp, cp, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_double,
+                               c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                               c_void_p, c_void_p]
+    L.mhd_cov_accumulate.argtypes = [pp, cp, c_int32, c_void_p]
+    for name in EXPORTS:
+        getattr(L, name)
+    if L.mhd_abi_version() != ABI_VERSION:
+        raise MhdError("libmcmc_amd.so ABI version mismatch; rebuild")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise MhdError(f"mhd call failed ({rc}): {lib().mhd_last_error().decode()}")

@@ -1,0 +1,500 @@
+// mhd_device.hpp -- device-side building blocks for gfx950 (wave64).
+//
+//   * LayerTable: one chain's layered half-space, staged in LDS
+//   * secular_rayleigh / secular_love: the period equation Delta(c)
+//   * WaveSearch: the sequential bracketing + interval-halving root search of
+//     disba's surf96 (reached from src/inversion/model_params.py:201-206 of the
+//     reference), executed by one 64-lane wave: the control flow is the
+//     sequential algorithm's, every secular value it consumes has really been
+//     evaluated at exactly the floating-point abscissa the sequential algorithm
+//     would use, and the 64 lanes evaluate the points it is about to need
+//     (the next scan points, or a 6-level tree of interval midpoints) at once.
+//
+// Floating-point discipline: everything that fixes an abscissa (start value,
+// scan steps, midpoints, stopping test) is compiled without fused multiply-add
+// so that the abscissae are bit-identical to a plain IEEE evaluation; only the
+// inside of the secular function, of which just the sign is used, may contract.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mcmc_amd.h"
+
+namespace mhd {
+
+constexpr int MAXL = MHD_MAX_LAYERS + 1;  // rows, last = half-space
+constexpr int MAXNP = 2 * MHD_MAX_LAYERS + 1;
+constexpr int MAXP = MHD_MAX_PERIODS;
+constexpr double TWOPI = 2.0 * 3.14159265358979323846;
+
+struct LayerTable {
+    double d[MAXL];      // thickness (km), last row unused
+    double a[MAXL];      // vp
+    double b[MAXL];      // vs
+    double rho[MAXL];    // density
+    double inv_a[MAXL];  // 1/vp
+    double inv_b[MAXL];  // 1/vs
+    double inv_rho[MAXL];
+    double twob2[MAXL];  // 2*vs^2
+    double cc;           // search floor: 0.9 * half-space Rayleigh velocity of the slowest layer
+    double betmx;        // largest vs
+    int L;
+};
+
+__device__ __forceinline__ int sgni(double x) { return (x > 0.0) - (x < 0.0); }
+
+// ---------------------------------------------------------------------------
+// Secular functions.  Only the sign of the result steers the search.
+// ---------------------------------------------------------------------------
+#pragma clang fp contract(fast)
+
+__device__ __forceinline__ void osc_or_evan(double k, double xk, double r, double arg,
+                                            double dpth, double& cs, double& over_r,
+                                            double& times_r, double& ex)
+{
+    // cs = cos / cosh-like term, over_r = sin/r, times_r = -/+ r*sin, ex = exponent pulled out
+    if (k < xk) {
+        double s, c;
+        sincos(arg, &s, &c);
+        cs = c;
+        over_r = s / r;
+        times_r = -r * s;
+        ex = 0.0;
+    } else if (k == xk) {
+        cs = 1.0;
+        over_r = dpth;
+        times_r = 0.0;
+        ex = 0.0;
+    } else {
+        double fac = (arg < 16.0) ? exp(-2.0 * arg) : 0.0;
+        cs = (1.0 + fac) * 0.5;
+        double sh = (1.0 - fac) * 0.5;
+        over_r = sh / r;
+        times_r = r * sh;
+        ex = arg;
+    }
+}
+
+__device__ __forceinline__ double secular_rayleigh(const LayerTable& T, double omega,
+                                                   double inv_om2, double c)
+{
+    const int L = T.L;
+    const double k = omega / c;
+    const double k2 = k * k;
+    int h = L - 1;
+    double xka = omega * T.inv_a[h];
+    double xkb = omega * T.inv_b[h];
+    double ra = sqrt((k + xka) * fabs(k - xka));
+    double rb = sqrt((k + xkb) * fabs(k - xkb));
+    double gammk = T.twob2[h] * inv_om2;
+    double gam = gammk * k2;
+    double gamm1 = gam - 1.0;
+    double rho1 = T.rho[h];
+    double e0 = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
+    double e1 = -rho1 * ra;
+    double e2 = rho1 * (gamm1 - gammk * ra * rb);
+    double e3 = rho1 * rb;
+    double e4 = k2 - ra * rb;
+
+    for (int m = L - 2; m >= 0; --m) {
+        xka = omega * T.inv_a[m];
+        xkb = omega * T.inv_b[m];
+        gammk = T.twob2[m] * inv_om2;
+        gam = gammk * k2;
+        ra = sqrt((k + xka) * fabs(k - xka));
+        rb = sqrt((k + xkb) * fabs(k - xkb));
+        const double dpth = T.d[m];
+        rho1 = T.rho[m];
+        const double irho = T.inv_rho[m];
+        double cosp, w, x, pex, cosq, y, z, sex;
+        osc_or_evan(k, xka, ra, ra * dpth, dpth, cosp, w, x, pex);
+        osc_or_evan(k, xkb, rb, rb * dpth, dpth, cosq, y, z, sex);
+        const double exa = pex + sex;
+        const double a0 = (exa < 60.0) ? exp(-exa) : 0.0;
+        const double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w,
+                     cqx = cosq * x, xy = x * y, xz = x * z, wy = w * y, wz = w * z;
+        gamm1 = gam - 1.0;
+        const double twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1,
+                     gm1sq = gamm1 * gamm1, rho2 = rho1 * rho1, a0pq = a0 - cpcq,
+                     t = -2.0 * k2;
+        const double ca00 = cpcq - 2.0 * gmgm1 * a0pq - gmgmk * xz - k2 * gm1sq * wy;
+        const double ca01 = (k2 * cpy - cqx) * irho;
+        const double ca02 = -(twgm1 * a0pq + gammk * xz + k2 * gamm1 * wy) * irho;
+        const double ca03 = (cpz - k2 * cqw) * irho;
+        const double ca04 = -(2.0 * k2 * a0pq + xz + k2 * k2 * wy) * (irho * irho);
+        const double ca10 = (gmgmk * cpz - gm1sq * cqw) * rho1;
+        const double ca11 = cpcq;
+        const double ca12 = gammk * cpz - gamm1 * cqw;
+        const double ca13 = -wz;
+        const double ca30 = (gm1sq * cpy - gmgmk * cqx) * rho1;
+        const double ca31 = -xy;
+        const double ca32 = gamm1 * cpy - gammk * cqx;
+        const double ca40 =
+            -(2.0 * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * xz + gm1sq * gm1sq * wy) * rho2;
+        const double ca42 =
+            -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * xz + gamm1 * gm1sq * wy) * rho1;
+        const double ca20 = t * ca42, ca21 = t * ca32, ca22 = a0 + 2.0 * (cpcq - ca00),
+                     ca23 = t * ca12, ca24 = t * ca02;
+        // ee_i = sum_j e_j ca_ji with ca14=ca03, ca33=ca11, ca34=ca01, ca41=ca30,
+        // ca43=ca10, ca44=ca00
+        const double n0 = e0 * ca00 + e1 * ca10 + e2 * ca20 + e3 * ca30 + e4 * ca40;
+        const double n1 = e0 * ca01 + e1 * ca11 + e2 * ca21 + e3 * ca31 + e4 * ca30;
+        const double n2 = e0 * ca02 + e1 * ca12 + e2 * ca22 + e3 * ca32 + e4 * ca42;
+        const double n3 = e0 * ca03 + e1 * ca13 + e2 * ca23 + e3 * ca11 + e4 * ca10;
+        const double n4 = e0 * ca04 + e1 * ca03 + e2 * ca24 + e3 * ca01 + e4 * ca00;
+        // rescale by an exact power of two (sign-preserving, no rounding)
+        const double t1 = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
+        const int ex = (t1 < 1.0e-40) ? 0 : -__builtin_amdgcn_frexp_exp(t1);
+        e0 = ldexp(n0, ex);
+        e1 = ldexp(n1, ex);
+        e2 = ldexp(n2, ex);
+        e3 = ldexp(n3, ex);
+        e4 = ldexp(n4, ex);
+    }
+    return e0;
+}
+
+__device__ __forceinline__ double secular_love(const LayerTable& T, double omega, double c)
+{
+    const int L = T.L;
+    const double k = omega / c;
+    int h = L - 1;
+    double xkb = omega * T.inv_b[h];
+    double rb = sqrt((k + xkb) * fabs(k - xkb));
+    double e1 = T.rho[h] * rb;
+    double e2 = T.inv_b[h] * T.inv_b[h];
+    for (int m = L - 2; m >= 0; --m) {
+        const double xmu = T.rho[m] * T.b[m] * T.b[m];
+        xkb = omega * T.inv_b[m];
+        rb = sqrt((k + xkb) * fabs(k - xkb));
+        const double dpth = T.d[m];
+        double cosq, y, z, sex;
+        osc_or_evan(k, xkb, rb, rb * dpth, dpth, cosq, y, z, sex);
+        const double e10 = e1 * cosq + e2 * xmu * z;
+        const double e20 = e1 * y / xmu + e2 * cosq;
+        const double xnor = fmax(fabs(e10), fabs(e20));
+        const int ex = (xnor < 1.0e-40) ? 0 : -__builtin_amdgcn_frexp_exp(xnor);
+        e1 = ldexp(e10, ex);
+        e2 = ldexp(e20, ex);
+    }
+    return e1;
+}
+
+__device__ __forceinline__ double secular(const LayerTable& T, int wave, double omega, double c)
+{
+    omega = fmax(omega, 1.0e-4);
+    if (wave == MHD_LOVE) return secular_love(T, omega, c);
+    return secular_rayleigh(T, omega, 1.0 / (omega * omega), c);
+}
+
+// ---------------------------------------------------------------------------
+// Everything below fixes abscissae: no contraction.
+// ---------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+// Half-space Rayleigh velocity, five Newton steps from 0.95*vs.
+__device__ inline double halfspace_rayleigh(double a, double b)
+{
+    double c = 0.95 * b;
+    for (int i = 0; i < 5; ++i) {
+        double gamma = b / a;
+        double kappa = c / b;
+        double k2 = kappa * kappa;
+        double gk2 = (gamma * kappa) * (gamma * kappa);
+        double fac1 = sqrt(1.0 - gk2);
+        double fac2 = sqrt(1.0 - k2);
+        double fr = (2.0 - k2) * (2.0 - k2) - 4.0 * fac1 * fac2;
+        double frp = -4.0 * (2.0 - k2) * kappa;
+        frp += 4.0 * fac2 * gamma * gamma * kappa / fac1;
+        frp += 4.0 * fac1 * kappa / fac2;
+        frp /= b;
+        c -= fr / frp;
+    }
+    return c;
+}
+
+// Build the LDS layer table from a parameter vector
+// [n_layers interface depths, n_layers+1 vs]  (model_params.py:187-198).
+// Called by every lane of the block; lanes < L fill one row each.
+__device__ inline void build_layer_table(LayerTable& T, const double* m, int n_layers, double vpvs,
+                                         int lane)
+{
+    const int L = n_layers + 1;
+    if (lane < L) {
+        double dep = (lane < n_layers) ? m[lane] : 0.0;
+        double prev = (lane > 0 && lane < n_layers) ? m[lane - 1] : 0.0;
+        double d = (lane < n_layers) ? dep - prev : 0.0;
+        double vs = m[n_layers + lane];
+        double vp = vs * vpvs;
+        double rho = (1741.0 * (double)sgni(vp) * pow(fabs(vp), 0.25)) / 1000.0;
+        T.d[lane] = d;
+        T.a[lane] = vp;
+        T.b[lane] = vs;
+        T.rho[lane] = rho;
+        T.inv_a[lane] = 1.0 / vp;
+        T.inv_b[lane] = 1.0 / vs;
+        T.inv_rho[lane] = 1.0 / rho;
+        T.twob2[lane] = 2.0 * vs * vs;
+    }
+    __syncthreads();
+    // extremal velocities and start value (uniform, every lane computes the same)
+    double betmx = -1.0e20, betmn = 1.0e20;
+    int jmn = 0, jsol = 1;
+    for (int i = 0; i < L; ++i) {
+        double bi = T.b[i], ai = T.a[i];
+        if (bi > 0.01 && bi < betmn) {
+            betmn = bi;
+            jmn = i;
+            jsol = 1;
+        } else if (bi <= 0.01 && ai < betmn) {
+            betmn = ai;
+            jmn = i;
+            jsol = 0;
+        }
+        if (bi > betmx) betmx = bi;
+    }
+    double cc = jsol ? halfspace_rayleigh(T.a[jmn], T.b[jmn]) : betmn;
+    cc *= 0.9;
+    if (lane == 0) {
+        T.cc = cc;
+        T.betmx = betmx;
+        T.L = L;
+    }
+    __syncthreads();
+}
+
+struct EvalCount {
+    unsigned long long lit;   // evaluations the sequential algorithm performs
+    unsigned long long exec;  // evaluations executed by lanes
+};
+
+// One advance of the sequential scan: from (c1, idir) to the next abscissa c2.
+__device__ __forceinline__ double scan_next(double& c1, int& idir, double clow, double dc)
+{
+    double c2;
+    for (;;) {
+        c2 = (idir > 0) ? c1 + dc : c1 - dc;
+        if (c2 <= clow) {
+            idir = +1;
+            c1 = clow;
+            continue;
+        }
+        break;
+    }
+    return c2;
+}
+
+// Bracket and refine one period (getsol), one wave.  All arguments are
+// wave-uniform.  s1st carries sign(del1st) between periods.  Returns success.
+__device__ inline bool solve_period_wave(const LayerTable& T, int wave, double t1, double& c1io,
+                                         double clow, double dc, double cm, double betmx,
+                                         bool ifirst, int& s1st, EvalCount& cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const double omega = TWOPI / t1;
+    double c1 = c1io, c2 = c1io;
+    int idir = +1, s1 = 0, s2 = 0;
+    bool have1 = false, bracketed = false;
+
+    // ---- scan ----
+    while (!bracketed) {
+        // lane j evaluates the abscissa the scan reaches after (have1 ? j+1 : j) advances
+        double pc1 = c1, pt = c1;
+        int pdir = idir;
+        const int nadv = have1 ? lane + 1 : lane;
+        for (int i = 0; i < nadv; ++i) {
+            pt = scan_next(pc1, pdir, clow, dc);
+            pc1 = pt;
+        }
+        const double del = secular(T, wave, omega, pt);
+        const unsigned long long neg = __ballot(del < 0.0), pos = __ballot(del > 0.0);
+        cnt.exec += 64;
+        int j = 0;
+        if (!have1) {
+            s1 = (int)((pos >> 0) & 1) - (int)((neg >> 0) & 1);
+            cnt.lit += 1;
+            have1 = true;
+            if (ifirst) s1st = s1;
+            idir = (ifirst || s1st * s1 >= 0) ? +1 : -1;
+            if (idir < 0) continue;  // speculated upward: evaluate the downward sequence
+            j = 1;
+        }
+        for (; j < 64; ++j) {
+            c2 = scan_next(c1, idir, clow, dc);
+            s2 = (int)((pos >> j) & 1) - (int)((neg >> j) & 1);
+            cnt.lit += 1;
+            if (s1 != s2) {
+                bracketed = true;
+                break;
+            }
+            c1 = c2;
+            s1 = s2;
+            if (c1 < cm || c1 >= betmx + dc) return false;
+        }
+    }
+
+    // ---- refine: pure interval halving, 6 levels of midpoints per batch ----
+    double c3 = 0.0;
+    int nctrl = 2;
+    bool done = false;
+    while (!done) {
+        double a = c1, b = c2;
+        const int t = lane ? lane : 1;
+        const int depth = 31 - __clz(t);
+        for (int lvl = depth - 1; lvl >= 0; --lvl) {
+            const double mid = 0.5 * (a + b);
+            if ((t >> lvl) & 1) a = mid; else b = mid;
+        }
+        const double pt = 0.5 * (a + b);
+        const double del = secular(T, wave, omega, pt);
+        const unsigned long long neg = __ballot(del < 0.0), pos = __ballot(del > 0.0);
+        cnt.exec += 64;
+        int node = 1;
+        while (node < 64) {
+            c3 = 0.5 * (c1 + c2);
+            const int s3 = (int)((pos >> node) & 1) - (int)((neg >> node) & 1);
+            cnt.lit += 1;
+            // the sequential loop applies at most 98 updates; the 99th midpoint is
+            // evaluated and returned without being applied
+            if (nctrl >= 100) {
+                done = true;
+                break;
+            }
+            if (s3 * s1 < 0) {
+                c2 = c3;
+                node = 2 * node;
+            } else {
+                c1 = c3;
+                s1 = s3;
+                node = 2 * node + 1;
+            }
+            if (fabs(c1 - c2) <= 1.0e-6 * c1) {
+                done = true;
+                break;
+            }
+            ++nctrl;
+        }
+    }
+    c1io = c3;
+    return c3 <= betmx;
+}
+
+// One phase-velocity curve (getc) for the table in T; t[] ascending periods,
+// c[] in LDS.  Wave-uniform.  Returns MHD_ST_OK or MHD_ST_NOROOT.
+__device__ inline int phase_curve_wave(const LayerTable& T, int wave, const double* t, int P,
+                                       double tscale, int mode, double dc, double* c,
+                                       EvalCount& cnt)
+{
+    if (T.b[0] <= 0.0) return MHD_ST_NOROOT;  // water layer: not part of this workload
+    const double cc = T.cc, betmx = T.betmx, cm = T.cc;
+    dc = fabs(dc);
+    const double one = 1.0e-2, onea = 1.5;
+    double c1 = cc, clow = cc;
+    int s1st = 0;
+    for (int k = 0; k < P; ++k) c[k] = 0.0;
+    for (int iq = 0; iq <= mode; ++iq) {
+        for (int k = 0; k < P; ++k) {
+            const bool ifirst = (k == 0);
+            if (ifirst && iq == 0) {
+                clow = cc;
+                c1 = cc;
+            } else if (ifirst && iq > 0) {
+                c1 = c[0] + one * dc;
+                clow = c1;
+            } else if (!ifirst && iq > 0) {
+                clow = c[k] + one * dc;
+                c1 = c[k - 1];
+                if (c1 < clow) c1 = clow;
+            } else {
+                clow = cm;
+                c1 = c[k - 1] - onea * dc;
+            }
+            const bool ok = solve_period_wave(T, wave, t[k] / tscale, c1, clow, dc, cm, betmx,
+                                              ifirst, s1st, cnt);
+            if (!ok) {
+                if (iq == 0) return MHD_ST_NOROOT;
+                for (int i = k; i < P; ++i) c[i] = 0.0;
+                break;
+            }
+            c[k] = c1;
+        }
+    }
+    return MHD_ST_OK;
+}
+
+// forward_model for the table in T: phase or group velocity into vel[] (LDS).
+// scratch must hold 2*P doubles (LDS).  Wave-uniform.
+__device__ inline int forward_wave(const LayerTable& T, int wave, int mode, int itype,
+                                   const double* t, int P, double dc, double dt, double* vel,
+                                   double* scratch, EvalCount& cnt)
+{
+    if (itype == MHD_PHASE) return phase_curve_wave(T, wave, t, P, 1.0, mode, dc, vel, cnt);
+    double* c1 = scratch;
+    double* c2 = scratch + P;
+    int st = phase_curve_wave(T, wave, t, P, 1.0 + dt, mode, dc, c1, cnt);
+    if (st != MHD_ST_OK) return st;
+    st = phase_curve_wave(T, wave, t, P, 1.0 - dt, mode, dc, c2, cnt);
+    if (st != MHD_ST_OK) return st;
+    for (int k = 0; k < P; ++k) {
+        if (c1[k] > 0.0 && c2[k] > 0.0) {
+            const double t1 = t[k] / (1.0 + dt), t2 = t[k] / (1.0 - dt);
+            const double f1 = 1.0 / t1, f2 = 1.0 / t2;
+            vel[k] = (f1 - f2) / (f1 / c1[k] - f2 / c2[k]);
+        } else {
+            vel[k] = 0.0;
+        }
+    }
+    return MHD_ST_OK;
+}
+
+// numpy float64 add.reduce order for a contiguous vector of n <= 128 entries.
+__device__ inline double npsum_small(const double* a, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i + 0];
+        r1 += a[i + 1];
+        r2 += a[i + 2];
+        r3 += a[i + 3];
+        r4 += a[i + 4];
+        r5 += a[i + 5];
+        r6 += a[i + 6];
+        r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+// Model.get_likelihood for one predicted curve in LDS; term[] is LDS scratch [P].
+__device__ inline double loglik_wave(const mhd_problem_t& p, const double* pred, double* term,
+                                     int lane)
+{
+    const int P = p.n_periods;
+    for (int k = lane; k < P; k += 64) {
+        const double r = p.obs[k] - pred[k];
+        if (p.noise_dist == MHD_NORMAL) {
+            const double s = p.noise_a[p.n_noise_a == 1 ? 0 : k];
+            term[k] = (r * r) / (2.0 * (s * s));
+        } else {
+            const double lam = p.noise_a[p.n_noise_a == 1 ? 0 : k];
+            const double kap = p.noise_b[p.n_noise_b == 1 ? 0 : k];
+            const int si = sgni(r);
+            const double s = (double)si;
+            const double kps = (si > 0) ? kap : ((si < 0) ? 1.0 / kap : 1.0);
+            term[k] = log(lam / (kap + (1.0 / kap))) - (((r * lam) * s) * kps);
+        }
+    }
+    __syncthreads();
+    const double sum = npsum_small(term, P);
+    __syncthreads();
+    return (p.noise_dist == MHD_NORMAL) ? -sum : sum;
+}
+
+}  // namespace mhd

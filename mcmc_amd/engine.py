@@ -1,0 +1,191 @@
+"""Batched device engine: thin Python over the C ABI.
+
+torch is used for device memory and streams only; all arithmetic of the hot
+path runs in the HIP kernels of mcmc_amd/csrc through include/mcmc_amd.h.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def noise_arrays(noise_dist, noise_params):
+    """(code, a, b) as the C ABI wants them.
+
+    normal: a = std, scalar or per period (src/inversion/model.py:430-432).
+    asym-laplace: a = lambd_scale*lambd clipped at lambd_max, b = kappa
+    (src/inversion/model.py:434-446).
+    """
+    if noise_dist == "normal":
+        return L.NORMAL, np.atleast_1d(np.asarray(noise_params["std"], dtype=np.float64)), None
+    if noise_dist == "asym-laplace":
+        lam = noise_params["lambd_scale"] * np.asarray(noise_params["lambd"], dtype=np.float64)
+        lam = np.atleast_1d(lam).copy()
+        if "lambd_max" in noise_params:
+            lam[lam >= noise_params["lambd_max"]] = noise_params["lambd_max"]
+        kap = np.atleast_1d(np.asarray(noise_params["kappa"], dtype=np.float64))
+        return L.ASYM_LAPLACE, lam, kap
+    raise ValueError(f"unknown noise_dist {noise_dist!r}")
+
+
+class DeviceProblem:
+    """Device-resident description of one inversion problem (struct mhd_problem)."""
+
+    def __init__(self, n_layers, vpvs, periods, obs=None, noise_dist="normal", noise_params=None,
+                 bounds=None, wave="rayleigh", mode=0, itype="phase", dc=0.005, dt=0.025,
+                 device=None):
+        L.lib()
+        if not torch.cuda.is_available():
+            raise L.MhdError("no GPU visible: the hot path has no CPU fallback")
+        self.device = torch.device(device if device is not None else
+                                   f"cuda:{torch.cuda.current_device()}")
+        self.n_layers = int(n_layers)
+        self.NP = 2 * self.n_layers + 1
+        periods = np.ascontiguousarray(periods, dtype=np.float64)
+        self.P = len(periods)
+        if self.n_layers < 1 or self.n_layers > L.MAX_LAYERS:
+            raise ValueError("n_layers outside the compiled limit")
+        if self.P < 1 or self.P > L.MAX_PERIODS:
+            raise ValueError("number of periods outside the compiled limit")
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.periods = torch.tensor(periods, **f64)
+        self.obs = None if obs is None else torch.tensor(np.asarray(obs, dtype=np.float64), **f64)
+        self.noise_a = self.noise_b = None
+        code, n_a, n_b = L.NORMAL, 1, 1
+        if noise_params is not None:
+            code, a, b = noise_arrays(noise_dist, noise_params)
+            self.noise_a = torch.tensor(a, **f64)
+            n_a = len(a)
+            if b is not None:
+                self.noise_b = torch.tensor(b, **f64)
+                n_b = len(b)
+        self.bounds = None if bounds is None else torch.tensor(
+            np.ascontiguousarray(bounds, dtype=np.float64), **f64)
+        self.c = L.Problem(
+            n_layers=self.n_layers, n_periods=self.P,
+            wave={"rayleigh": L.RAYLEIGH, "love": L.LOVE}[wave], mode=int(mode),
+            itype={"phase": L.PHASE, "group": L.GROUP}[itype], noise_dist=code, n_noise_a=n_a,
+            n_noise_b=n_b, vpvs=float(vpvs), dc=float(dc), dt=float(dt),
+            periods=self.periods.data_ptr(),
+            obs=None if self.obs is None else self.obs.data_ptr(),
+            noise_a=None if self.noise_a is None else self.noise_a.data_ptr(),
+            noise_b=None if self.noise_b is None else self.noise_b.data_ptr(),
+            bounds=None if self.bounds is None else self.bounds.data_ptr())
+
+    # -- forward_model for a batch (src/inversion/model_params.py:178-209) --
+    def forward(self, params, n_evals=None):
+        """params [B,NP] device tensor -> (vel [B,P], status [B] int32)."""
+        params = params.contiguous()
+        B = params.shape[0]
+        assert params.shape[1] == self.NP and params.dtype == torch.float64
+        vel = torch.empty((B, self.P), dtype=torch.float64, device=self.device)
+        status = torch.empty(B, dtype=torch.int32, device=self.device)
+        L.check(L.lib().mhd_forward_batch(ctypes.byref(self.c), _ptr(params), B, _ptr(vel),
+                                          _ptr(status), _ptr(n_evals), _stream()))
+        return vel, status
+
+    def secular(self, params, chain, period, c):
+        params = params.contiguous()
+        N = chain.numel()
+        delta = torch.empty(N, dtype=torch.float64, device=self.device)
+        L.check(L.lib().mhd_secular_batch(ctypes.byref(self.c), _ptr(params), params.shape[0],
+                                          _ptr(chain), _ptr(period), _ptr(c), N, _ptr(delta),
+                                          _stream()))
+        return delta
+
+    # -- Model.get_likelihood for a batch (src/inversion/model.py:420-447) --
+    def loglik(self, pred):
+        pred = pred.contiguous()
+        B = pred.shape[0]
+        out = torch.empty(B, dtype=torch.float64, device=self.device)
+        L.check(L.lib().mhd_loglik_batch(ctypes.byref(self.c), _ptr(pred), B, _ptr(out),
+                                         _stream()))
+        return out
+
+
+class DeviceChains:
+    """State of B chains on the device (struct mhd_chains)."""
+
+    def __init__(self, prob, m, width, beta=None, individual_acceptance=False):
+        self.prob = prob
+        dev = prob.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.m = torch.as_tensor(np.asarray(m, dtype=np.float64), **f64).contiguous() \
+            if not torch.is_tensor(m) else m.to(**f64).contiguous()
+        self.B = B = self.m.shape[0]
+        NP, P = prob.NP, prob.P
+        assert self.m.shape[1] == NP
+        w = np.broadcast_to(np.asarray(width, dtype=np.float64), (B, NP))
+        self.width = torch.tensor(np.ascontiguousarray(w), **f64)
+        self.logL = torch.zeros(B, **f64)
+        self.pred = torch.zeros((B, P), **f64)
+        self.params_prev = torch.zeros((B, NP), **f64)
+        self.rot = torch.eye(NP, **f64).repeat(B, 1, 1).contiguous()
+        self.cov_sum = torch.zeros((B, NP, NP), **f64)
+        self.n_cov = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.counters = torch.zeros((B, 5), dtype=torch.int64, device=dev)
+        self.counters_ind = torch.zeros((B, NP, 5), dtype=torch.int64, device=dev) \
+            if individual_acceptance else None
+        self.beta = None if beta is None else torch.tensor(
+            np.asarray(beta, dtype=np.float64), **f64)
+        self.n_evals = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def struct(self):
+        return L.Chains(
+            m=self.m.data_ptr(), logL=self.logL.data_ptr(), pred=self.pred.data_ptr(),
+            params_prev=self.params_prev.data_ptr(), width=self.width.data_ptr(),
+            rot=self.rot.data_ptr(), cov_sum=self.cov_sum.data_ptr(),
+            n_cov=self.n_cov.data_ptr(), counters=self.counters.data_ptr(),
+            counters_ind=None if self.counters_ind is None else self.counters_ind.data_ptr(),
+            beta=None if self.beta is None else self.beta.data_ptr())
+
+    def init_likelihood(self):
+        """pred, logL of the current parameters; returns status [B]."""
+        vel, status = self.prob.forward(self.m)
+        self.pred.copy_(vel)
+        self.logL.copy_(self.prob.loglik(vel))
+        return status
+
+    def steps(self, idx, cauchy, u_acc, T=1.0, rotate=0, sample_prior=False, hist_every=0,
+              want_flags=True):
+        """Run S = idx.shape[0] Metropolis-Hastings steps for every chain.
+
+        idx [S,B] int32, cauchy [S,B], u_acc [S,B] are device tensors of host-supplied draws.
+        Returns dict with accepted [S,B] uint8, status [S,B] int32 and, when hist_every > 0,
+        hist_m [S//hist_every,B,NP] and hist_logL [S//hist_every,B].
+        """
+        S, B = idx.shape
+        assert B == self.B and cauchy.shape == (S, B) and u_acc.shape == (S, B)
+        assert idx.dtype == torch.int32 and idx.is_contiguous()
+        dev = self.prob.device
+        out = {}
+        acc = st = hm = hl = None
+        if want_flags:
+            acc = torch.empty((S, B), dtype=torch.uint8, device=dev)
+            st = torch.empty((S, B), dtype=torch.int32, device=dev)
+            out["accepted"], out["status"] = acc, st
+        if hist_every > 0:
+            hm = torch.empty((S // hist_every, B, self.prob.NP), dtype=torch.float64, device=dev)
+            hl = torch.empty((S // hist_every, B), dtype=torch.float64, device=dev)
+            out["hist_m"], out["hist_logL"] = hm, hl
+        ch = self.struct()
+        L.check(L.lib().mhd_mh_steps(
+            ctypes.byref(self.prob.c), ctypes.byref(ch), B, S, _ptr(idx), _ptr(cauchy.contiguous()),
+            _ptr(u_acc.contiguous()), float(T), int(rotate), int(bool(sample_prior)), _ptr(acc),
+            _ptr(st), int(hist_every), _ptr(hm), _ptr(hl), _ptr(self.n_evals), _stream()))
+        return out
+
+    def cov_accumulate(self):
+        ch = self.struct()
+        L.check(L.lib().mhd_cov_accumulate(ctypes.byref(self.prob.c), ctypes.byref(ch), self.B,
+                                           _stream()))

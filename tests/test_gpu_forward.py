@@ -1,0 +1,118 @@
+"""GPU parity: HIP forward model and likelihood against the CPU oracle (through the C ABI)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def prior_draws(rng, n, n_layers, lo_d=0.001, hi_d=0.15, lo_v=0.1, hi_v=2.0):
+    d = np.sort(rng.uniform(lo_d, hi_d, (n, n_layers)), axis=1)
+    v = rng.uniform(lo_v, hi_v, (n, n_layers + 1))
+    return np.concatenate([d, v], axis=1)
+
+
+def compare_curves(vel, status, ovel, ost):
+    """Bit-exact abscissae are expected; report how many are not and bound them at 1e-8."""
+    assert (status == ost).all(), f"status differs on {np.flatnonzero(status != ost)[:10]}"
+    ok = ost == 0
+    rel = np.abs(vel[ok] - ovel[ok]) / np.abs(ovel[ok])
+    n_diff = int((vel[ok] != ovel[ok]).sum())
+    return rel.max() if rel.size else 0.0, n_diff, int(ok.sum())
+
+
+@pytest.mark.parametrize("n_layers,P,B", [(2, 100, 64), (3, 20, 256), (6, 40, 1024), (12, 40, 128)])
+def test_forward_matches_oracle(torch_cuda, oracle, n_layers, P, B):
+    torch = torch_cuda
+    from mcmc_amd.engine import DeviceProblem
+    rng = np.random.default_rng(100 + n_layers)
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    params = prior_draws(rng, B, n_layers)
+    prob = DeviceProblem(n_layers, 1.75, periods)
+    ne = torch.zeros(2, dtype=torch.int64, device=prob.device)
+    vel, status = prob.forward(torch.tensor(params, device=prob.device), n_evals=ne)
+    ost, ovel, one = oracle.forward_batch(params, n_layers, 1.75, periods, nthreads=8)
+    vel, status = vel.cpu().numpy(), status.cpu().numpy()
+    rel, n_diff, n_ok = compare_curves(vel, status, ovel, ost)
+    # tolerance of the north star: 1e-8 relative
+    assert rel <= 1e-8, (rel, n_diff)
+    # the kernel consumes exactly the evaluations the sequential algorithm performs
+    assert int(ne[0]) == one
+    print(f"L={n_layers} P={P} B={B}: ok={n_ok} max_rel={rel:.2e} non-identical={n_diff} "
+          f"evals lit={int(ne[0])} exec={int(ne[1])}")
+
+
+def test_forward_golden_curves(torch_cuda):
+    """The disba curves embedded in the reference, straight through the HIP path."""
+    torch = torch_cuda
+    from mcmc_amd.engine import DeviceProblem
+    g = load_golden("disba_curves.json")
+    periods = np.flip(1 / np.logspace(0, 1.1, 100)).copy()
+    prob = DeviceProblem(2, 1.75, periods)
+    params = np.array([c["params"] for c in g["curves"]])
+    vel, status = prob.forward(torch.tensor(params, device=prob.device))
+    vel = vel.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all()
+    for v, c in zip(vel, g["curves"]):
+        ref = np.array(c["velocity"])
+        assert (np.abs(v - ref) / ref).max() <= 2e-6
+
+
+def test_secular_sign_and_value(torch_cuda, oracle):
+    torch = torch_cuda
+    from mcmc_amd.engine import DeviceProblem
+    rng = np.random.default_rng(5)
+    nl, P, B, N = 6, 40, 32, 4096
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    params = prior_draws(rng, B, nl)
+    prob = DeviceProblem(nl, 1.75, periods)
+    chain = rng.integers(0, B, N).astype(np.int32)
+    per = rng.integers(0, P, N).astype(np.int32)
+    c = rng.uniform(0.08, 2.2, N)
+    dev = prob.device
+    d = prob.secular(torch.tensor(params, device=dev), torch.tensor(chain, device=dev),
+                     torch.tensor(per, device=dev), torch.tensor(c, device=dev)).cpu().numpy()
+    n_sign = 0
+    for i in range(N):
+        tab = oracle.layer_table(params[chain[i]], nl, 1.75)
+        od = oracle.secular(*tab, periods[per[i]], c[i])
+        # the oracle divides by the largest component, the kernel by a power of two:
+        # compare signs, and values up to that positive scale
+        if np.sign(od) != np.sign(d[i]):
+            n_sign += 1
+            assert abs(od) < 1e-9, (i, od, d[i])
+    assert n_sign <= 2
+
+
+@pytest.mark.parametrize("noise", ["normal_scalar", "normal_vector", "asym_laplace"])
+def test_loglik_matches_oracle(torch_cuda, oracle, noise):
+    torch = torch_cuda
+    from mcmc_amd.engine import DeviceProblem
+    rng = np.random.default_rng(9)
+    for P in (5, 8, 20, 40, 61, 128):
+        periods = np.linspace(0.05, 0.5, P)
+        obs = rng.uniform(0.2, 0.9, P)
+        pred = obs + 0.02 * rng.standard_normal((64, P))
+        if noise == "normal_scalar":
+            dist, par = "normal", {"std": 0.025}
+        elif noise == "normal_vector":
+            dist, par = "normal", {"std": rng.uniform(0.01, 0.05, P)}
+        else:
+            dist, par = "asym-laplace", {"lambd_scale": 1.2, "lambd": rng.uniform(20, 80, P),
+                                         "kappa": rng.uniform(0.5, 1.5, P), "lambd_max": 70.0}
+        prob = DeviceProblem(3, 1.75, periods, obs, dist, par,
+                             bounds=np.tile([0.0, 1.0, 1.0], (7, 1)))
+        got = prob.loglik(torch.tensor(pred, device=prob.device)).cpu().numpy()
+        want = np.array([oracle.loglik(obs, p, dist, par) for p in pred])
+        if dist == "normal":
+            np.testing.assert_array_equal(got, want)   # numpy summation order, bit exact
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-9)  # north-star tolerance
