@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Metropolis-Hastings steps per second, 6-layer Rayleigh
+phase-velocity inversion, 1024 chains x 40 periods per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one Model.perturb_params for every chain of the batch (one
+proposal, at most one forward curve, one likelihood, one accept test per
+chain).  Chains are independent, so ranks share nothing on the data path
+(weak scaling: 1024 chains per GPU); the only collective is the timing
+barrier / max-reduction.  Inputs are synthetic and seeded: periods
+np.flip(1/np.logspace(0.3, 1.3, 40)), vpvs 1.75, Gardner density, bounds
+depth [0.001, 0.15] km and vs [0.1, 2.0] km/s, proposal width 0.05, Cauchy
+proposal, Gaussian likelihood std 0.025, starts drawn from the prior until the
+forward model succeeds, draws from default_rng(0).
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_LAYERS, VPVS, N_PERIODS, CHAINS_PER_GPU = 6, 1.75, 40, 1024
+TRUE_M = np.array([0.01, 0.02, 0.04, 0.06, 0.08, 0.10, 0.2, 0.3, 0.45, 0.6, 0.8, 1.0, 1.5])
+STD = 0.025
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+
+
+def flops_per_eval(rows, wave="rayleigh"):
+    """Algorithmic flops of one secular evaluation (+,-,*,/,sqrt,sin,cos,exp = 1 each)."""
+    return 31 + 172 * (rows - 1) if wave == "rayleigh" else 8 + 25 * (rows - 1)
+
+
+def problem_inputs():
+    periods = np.flip(1 / np.logspace(0.3, 1.3, N_PERIODS)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * N_LAYERS + [[0.1, 2.0, 1.9]] * (N_LAYERS + 1))
+    return periods, bounds
+
+
+def prior_starts(prob, bounds, n, rng):
+    """Independent prior draws (model.py:94-105) kept when the forward model succeeds."""
+    import torch
+    out = np.empty((0, bounds.shape[0]))
+    while out.shape[0] < n:
+        cand = rng.uniform(bounds[:, 0], bounds[:, 1], size=(2 * n, bounds.shape[0]))
+        nl = N_LAYERS
+        order = np.argsort(cand[:, :nl], axis=1, kind="stable")
+        cand[:, :nl] = np.take_along_axis(cand[:, :nl], order, axis=1)
+        cand[:, nl:2 * nl] = np.take_along_axis(cand[:, nl:2 * nl], order, axis=1)
+        _, st = prob.forward(torch.tensor(cand, device=prob.device))
+        out = np.concatenate([out, cand[st.cpu().numpy() == 0]])
+    return out[:n]
+
+
+def cpu_baseline(periods, bounds, obs, starts, seed, budget_s=12.0):
+    """The CPU oracle's MH loop on a bounded sample of the same workload."""
+    import oracle
+    nl, NP = N_LAYERS, 2 * N_LAYERS + 1
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    noise = {"std": STD}
+    rng = np.random.default_rng(seed)
+    res = {}
+    for label, nt, B in (("1core", 1, 64), ("allcores", cores, min(len(starts), 16 * cores))):
+        m = starts[:B]
+        st, vel, _ = oracle.forward_batch(m, nl, VPVS, periods, nthreads=nt)
+        logL = np.array([oracle.loglik(obs, v, "normal", noise) for v in vel])
+        S = oracle.ChainState(m, logL, vel, 0.05, bounds)
+        oracle.set_threads(nt)
+        n_steps, t0 = 0, time.perf_counter()
+        while True:
+            idx = rng.integers(0, NP, B).astype(np.int32)
+            cz = np.tan(np.pi * (rng.uniform(size=B) - 0.5))
+            ua = rng.uniform(size=B)
+            oracle.mh_step(S, idx, cz, ua, nl, VPVS, periods, obs, "normal", noise)
+            n_steps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s / 2 or n_steps >= 400:
+                break
+        res[label] = (B * n_steps / dt, nt, B, n_steps)
+        oracle.set_threads(1)
+    v, nt, B, n = res["allcores"]
+    return {
+        "value": v, "unit": "MH steps/s", "cores": nt, "kind": "port",
+        "sample": f"{B} chains x {n} steps of the same 6-layer/40-period workload, "
+                  f"OpenMP over chains; 1 core: {res['1core'][0]:.1f} steps/s "
+                  f"({res['1core'][2]} chains x {res['1core'][3]} steps)",
+        "value_1core": res["1core"][0],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--chunk", type=int, default=250, help="MH steps per kernel launch")
+    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    periods, bounds = problem_inputs()
+    B, NP, K, W = args.chains, 2 * N_LAYERS + 1, args.steps, args.warmup
+    # data: true curve + N(0, std^2); the true curve comes from the product path
+    prob0 = DeviceProblem(N_LAYERS, VPVS, periods)
+    true_curve, st = prob0.forward(torch.tensor(TRUE_M[None, :], device=prob0.device))
+    assert int(st[0]) == 0
+    np.random.seed(0)
+    obs = true_curve[0].cpu().numpy() + STD * np.random.randn(N_PERIODS)
+    prob = DeviceProblem(N_LAYERS, VPVS, periods, obs, "normal", {"std": STD}, bounds)
+    rng = np.random.default_rng(1000 + rank)
+    starts = prior_starts(prob, bounds, B, rng)
+    chains = DeviceChains(prob, starts, 0.05)
+    assert int((chains.init_likelihood() != 0).sum()) == 0
+
+    drng = np.random.default_rng(rank)  # default_rng(0) on rank 0
+    total = W + K
+    dev = prob.device
+    idx = torch.tensor(drng.integers(0, NP, (total, B)).astype(np.int32), device=dev)
+    cauchy = torch.tensor(np.tan(np.pi * (drng.uniform(size=(total, B)) - 0.5)), device=dev)
+    u_acc = torch.tensor(drng.uniform(size=(total, B)), device=dev)
+
+    def run(lo, hi):
+        n_launch = 0
+        for a in range(lo, hi, args.chunk):
+            b = min(hi, a + args.chunk)
+            chains.steps(idx[a:b], cauchy[a:b], u_acc[a:b], want_flags=False)
+            n_launch += 1
+        return n_launch
+
+    run(0, W)
+    torch.cuda.synchronize()
+    chains.n_evals.zero_()
+    acc0 = chains.counters[:, 0].sum().item()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    n_launch = run(W, total)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    lit, ex = (int(x) for x in chains.n_evals.tolist())
+    acc_rate = (chains.counters[:, 0].sum().item() - acc0) / (B * K)
+
+    if rank == 0:
+        F = flops_per_eval(N_LAYERS + 1)
+        launch_s = kernel_ms * 1e-3 / n_launch
+        achieved = lit * F / n_launch / launch_s / 1e12
+        line = {
+            "metric": "MH steps/sec (whole node), 6-layer Rayleigh, 1024 chains x 40 periods",
+            "value": world * B * K / elapsed,
+            "unit": "MH steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: 6-layer Rayleigh fundamental-mode phase-velocity "
+                            "inversion, 1024 independent chains x 40 periods per GPU",
+                "chains_per_gpu": B, "n_periods": N_PERIODS, "n_layers": N_LAYERS,
+                "proposal": "cauchy", "likelihood": "normal", "rotation": "off",
+                "steps_per_launch": args.chunk, "acceptance_rate": round(acc_rate, 4),
+            },
+            "roofline": {
+                "bound": "valu_fp64",
+                "achieved": achieved,
+                "peak": FP64_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                "traffic": None,
+                "kernel": "mh_steps_kernel",
+                "launch_ms": launch_s * 1e3,
+                "algorithmic_evals_per_launch": lit / n_launch,
+                "executed_evals_per_launch": ex / n_launch,
+                "flops_per_eval": F,
+            },
+        }
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(periods, bounds, obs, starts, seed=7)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

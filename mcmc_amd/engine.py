@@ -167,6 +167,9 @@ class DeviceChains:
         S, B = idx.shape
         assert B == self.B and cauchy.shape == (S, B) and u_acc.shape == (S, B)
         assert idx.dtype == torch.int32 and idx.is_contiguous()
+        assert cauchy.dtype == torch.float64 and u_acc.dtype == torch.float64, \
+            "draws must be float64"
+        cauchy, u_acc = cauchy.contiguous(), u_acc.contiguous()
         dev = self.prob.device
         out = {}
         acc = st = hm = hl = None
@@ -180,8 +183,8 @@ class DeviceChains:
             out["hist_m"], out["hist_logL"] = hm, hl
         ch = self.struct()
         L.check(L.lib().mhd_mh_steps(
-            ctypes.byref(self.prob.c), ctypes.byref(ch), B, S, _ptr(idx), _ptr(cauchy.contiguous()),
-            _ptr(u_acc.contiguous()), float(T), int(rotate), int(bool(sample_prior)), _ptr(acc),
+            ctypes.byref(self.prob.c), ctypes.byref(ch), B, S, _ptr(idx), _ptr(cauchy),
+            _ptr(u_acc), float(T), int(rotate), int(bool(sample_prior)), _ptr(acc),
             _ptr(st), int(hist_every), _ptr(hm), _ptr(hl), _ptr(self.n_evals), _stream()))
         return out
 

@@ -58,6 +58,8 @@ def lib():
             _dp, _dp, _dp, _dp, _dp, _dp, _dp, _lp, _lp, _dp, _dp, c_double, c_int, c_int,
             c_double, _dp, c_int, _dp, c_int, _dp, c_int, _dp, c_int, c_int, c_int, c_int,
             c_double, c_double, c_int, c_int, _ip, _dp, _dp, _bp, _ip, _llp]
+        L.orc_set_threads.restype = None
+        L.orc_set_threads.argtypes = [c_int]
         L.orc_cov_accumulate.restype = None
         L.orc_cov_accumulate.argtypes = [_dp, _dp, _dp, _lp, _dp, c_int, c_int]
         _lib = L
@@ -198,3 +200,8 @@ def cov_accumulate(state):
     """update_covariance_matrix alone (model.py:263-282)."""
     lib().orc_cov_accumulate(_d(state.m), _d(state.params_prev), _d(state.cov_sum),
                              state.n_cov.ctypes.data_as(_lp), _d(state.bounds), state.B, state.NP)
+
+
+def set_threads(n):
+    """Threads orc_mh_step spreads the chains over (1 = scalar)."""
+    lib().orc_set_threads(int(n))

@@ -1,0 +1,142 @@
+"""GPU parity of the Metropolis-Hastings step: against traces of the reference's own
+Model.perturb_params (tests/golden/mh_trace_*.json) and against the CPU oracle, through the
+C ABI.  Parameters and accept/reject decisions must be identical; logL within 1e-9."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise(g):
+    return {k: (np.array(v) if isinstance(v, list) else v) for k, v in g["noise_params"].items()}
+
+
+@pytest.mark.parametrize("case", ["3layer_normal", "6layer_normal", "6layer_asymlaplace",
+                                  "3layer_individual_T2"])
+def test_reference_trace(case):
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    g = load_golden(f"mh_trace_{case}.json")
+    nl = g["n_layers"]
+    prob = DeviceProblem(nl, g["vpvs"], g["periods"], g["obs"], g["noise_dist"], _noise(g),
+                         g["bounds"])
+    ch = DeviceChains(prob, np.array([g["start"]]), g["width0"],
+                      individual_acceptance=g["individual_acceptance"])
+    assert int(ch.init_likelihood()[0]) == 0
+    tol = 1e-13 if g["noise_dist"] == "asym-laplace" else 0.0
+    assert ch.logL.item() == pytest.approx(g["start_logL"], rel=tol, abs=0)
+    S = len(g["steps"])
+    dev = prob.device
+    idx = torch.tensor(np.array(g["idx"], dtype=np.int32)[:, None], device=dev)
+    cauchy = torch.tensor(np.tan(np.pi * (np.array(g["u_prop"]) - 0.5))[:, None], device=dev)
+    u_acc = torch.tensor(np.array(g["u_acc"])[:, None], device=dev)
+    out = ch.steps(idx, cauchy, u_acc, T=g["T"], hist_every=1)
+    hist_m = out["hist_m"].cpu().numpy()[:, 0]
+    hist_l = out["hist_logL"].cpu().numpy()[:, 0]
+    status = out["status"].cpu().numpy()[:, 0]
+    want_m = np.array([r["m"] for r in g["steps"]])
+    want_l = np.array([r["logL"] for r in g["steps"]])
+    np.testing.assert_array_equal(hist_m, want_m)            # bit exact
+    np.testing.assert_allclose(hist_l, want_l, rtol=1e-9)    # north-star tolerance
+    if g["noise_dist"] == "normal":
+        np.testing.assert_array_equal(hist_l, want_l)
+    # the reference draws the accept uniform only for valid proposals
+    assert [2 if s == 0 else 1 for s in status] == [r["n_uniform_draws"] for r in g["steps"]]
+    last = g["steps"][-1]
+    cnt = ch.counters.cpu().numpy()[0]
+    if g["individual_acceptance"]:
+        ci = ch.counters_ind.cpu().numpy()[0]
+        np.testing.assert_array_equal(ci[:, 0], last["n_acc"])
+        np.testing.assert_array_equal(ci[:, 1], last["n_rej"])
+        np.testing.assert_array_equal(ci[:, 2], last["n_bounds_err"])
+    else:
+        assert cnt[0] == last["n_acc"] and cnt[1] == last["n_rej"]
+        assert cnt[2] == last["n_bounds_err"] and cnt[4] == last["n_fm_err"]
+    np.testing.assert_array_equal(ch.pred.cpu().numpy()[0], g["final_pred"])
+
+
+@pytest.mark.parametrize("n_layers,P,B,S", [(3, 20, 64, 60), (6, 40, 256, 40)])
+def test_batched_steps_vs_oracle(oracle, n_layers, P, B, S):
+    """Many chains from prior draws (includes forward failures and bounds rejections)."""
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    rng = np.random.default_rng(42 + n_layers)
+    nl, NP = n_layers, 2 * n_layers + 1
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
+    starts = []
+    while len(starts) < B:
+        x = oracle.sort_layers(rng.uniform(bounds[:, 0], bounds[:, 1]), nl)
+        if oracle.forward(x, nl, 1.75, periods)[0] == 0:
+            starts.append(x)
+    starts = np.array(starts)
+    obs = oracle.forward(starts[0], nl, 1.75, periods)[1] + 0.025 * rng.standard_normal(P)
+    noise = {"std": 0.025}
+    beta = rng.choice([1.0, 0.7, 0.3], B)
+    prob = DeviceProblem(nl, 1.75, periods, obs, "normal", noise, bounds)
+    ch = DeviceChains(prob, starts, 0.05, beta=beta)
+    assert int((ch.init_likelihood() != 0).sum()) == 0
+    _, ovel, _ = oracle.forward_batch(starts, nl, 1.75, periods)
+    ologL = np.array([oracle.loglik(obs, v, "normal", noise) for v in ovel])
+    ost = oracle.ChainState(starts, ologL, ovel, 0.05, bounds)
+    idx = rng.integers(0, NP, (S, B)).astype(np.int32)
+    cauchy = np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5))
+    u_acc = rng.uniform(size=(S, B))
+    dev = prob.device
+    out = ch.steps(torch.tensor(idx, device=dev), torch.tensor(cauchy, device=dev),
+                   torch.tensor(u_acc, device=dev))
+    acc = np.zeros((S, B), dtype=np.uint8)
+    stat = np.zeros((S, B), dtype=np.int32)
+    lit = 0
+    for s in range(S):
+        acc[s], stat[s], ne = oracle.mh_step(ost, idx[s], cauchy[s], u_acc[s], nl, 1.75, periods,
+                                             obs, "normal", noise, beta=beta)
+        lit += ne
+    np.testing.assert_array_equal(out["accepted"].cpu().numpy(), acc)
+    np.testing.assert_array_equal(out["status"].cpu().numpy(), stat)
+    np.testing.assert_array_equal(ch.m.cpu().numpy(), ost.m)
+    np.testing.assert_allclose(ch.logL.cpu().numpy(), ost.logL, rtol=1e-9)
+    np.testing.assert_allclose(ch.pred.cpu().numpy(), ost.pred, rtol=1e-8)
+    np.testing.assert_array_equal(ch.counters.cpu().numpy(), ost.counters)
+    assert int(ch.n_evals[0]) == lit
+    assert (stat == 1).any()   # bounds rejections were exercised
+
+
+def test_rotation_trace(oracle):
+    """Covariance accumulation + rotated-frame proposals against the reference trace (the
+    reference's matvec is BLAS, so parameters agree to rounding, not bit for bit)."""
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    g = load_golden("mh_trace_3layer_rotate.json")
+    nl = g["n_layers"]
+    prob = DeviceProblem(nl, g["vpvs"], g["periods"], g["obs"], g["noise_dist"], _noise(g),
+                         g["bounds"])
+    ch = DeviceChains(prob, np.array([g["start"]]), g["width0"])
+    assert int(ch.init_likelihood()[0]) == 0
+    dev = prob.device
+    cauchy = np.tan(np.pi * (np.array(g["u_prop"]) - 0.5))
+    for s, rec in enumerate(g["steps"]):
+        n_step, thin = divmod(s, g["n_thin"])
+        burn = n_step < g["n_burn"]
+        upd = (n_step >= g["n_burn"] + g["n_cov_chunk"] + 2 and n_step % g["n_cov_chunk"] == 0
+               and thin == 0)
+        rot = 1
+        if upd:
+            ch.cov_accumulate()
+            cov = (ch.cov_sum[0] / ch.n_cov[0]).cpu().numpy()
+            U, sv, _ = np.linalg.svd(cov)
+            ch.rot[0] = torch.tensor(U, device=dev)
+            ch.width[0] = torch.tensor(np.sqrt(sv), device=dev)
+            rot = 0
+        if not burn:
+            rot |= 2
+        ch.steps(torch.tensor([[g["idx"][s]]], dtype=torch.int32, device=dev),
+                 torch.tensor([[cauchy[s]]], dtype=torch.float64, device=dev),
+                 torch.tensor([[g["u_acc"][s]]], dtype=torch.float64, device=dev), rotate=rot)
+        assert int(ch.n_cov[0]) == rec["n_cov"], s
+        np.testing.assert_allclose(ch.m[0].cpu().numpy(), rec["m"], rtol=1e-9, err_msg=str(s))
+        assert int(ch.counters[0, 0]) == rec["n_acc"]
+    np.testing.assert_allclose(ch.cov_sum[0].cpu().numpy(), g["final_cov_sum"], rtol=1e-9,
+                               atol=1e-18)
