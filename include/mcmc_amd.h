@@ -149,15 +149,17 @@ int mhd_loglik_batch(const mhd_problem_t *prob, const double *pred /* device [B,
  * rotate is a mask of MHD_ROT_*.  sample_prior != 0 skips the forward model
  * and uses logL_new = 1 (model.py:234-236).
  * Optional outputs (NULL to skip): accepted[S,B] (uint8), status[S,B],
- * hist_m[S/hist_every,B,NP], hist_logL[S/hist_every,B] written after every
- * hist_every-th step.  n_evals as in mhd_forward_batch.
+ * hist_m[S/hist_every,B,NP], hist_logL[S/hist_every,B], hist_pred[S/hist_every,B,P]
+ * written after every hist_every-th step (the per-step records of
+ * Inversion.store_samples, src/inversion/inversion.py:431-457).  n_evals as in
+ * mhd_forward_batch.
  */
 int mhd_mh_steps(const mhd_problem_t *prob, const mhd_chains_t *chains, int32_t B,
                  int32_t n_steps, const int32_t *idx /* device [S,B] */,
                  const double *cauchy /* device [S,B] */, const double *u_acc /* device [S,B] */,
                  double T, int32_t rotate, int32_t sample_prior,
                  uint8_t *accepted, int32_t *status, int32_t hist_every, double *hist_m,
-                 double *hist_logL, uint64_t *n_evals, void *stream);
+                 double *hist_logL, double *hist_pred, uint64_t *n_evals, void *stream);
 
 /*
  * Model.update_covariance_matrix alone (src/inversion/model.py:263-282), used on

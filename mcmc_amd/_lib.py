@@ -79,7 +79,7 @@ def lib():
     L.mhd_loglik_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p]
     L.mhd_mh_steps.argtypes = [pp, cp, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_double,
                                c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
-                               c_void_p, c_void_p]
+                               c_void_p, c_void_p, c_void_p]
     L.mhd_cov_accumulate.argtypes = [pp, cp, c_int32, c_void_p]
     for name in EXPORTS:
         getattr(L, name)

@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mhd_api.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "mhd_device.hpp"),
+DEPS = [SRC, os.path.join(HERE, "csrc", "mhd_device.hpp"), os.path.join(HERE, "csrc", "mhd_math.hpp"),
         os.path.join(os.path.dirname(HERE), "include", "mcmc_amd.h")]
 OUT = os.path.join(HERE, "lib", "libmcmc_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

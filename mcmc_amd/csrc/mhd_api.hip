@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) void cov_kernel(mhd_problem_t p, mhd_chains_t c
 __global__ __launch_bounds__(64) void mh_steps_kernel(
     mhd_problem_t p, mhd_chains_t ch, int B, int S, const int32_t* idx, const double* cauchy,
     const double* u_acc, double Temp, int rotate, int sample_prior, uint8_t* accepted,
-    int32_t* status, int hist_every, double* hist_m, double* hist_logL,
+    int32_t* status, int hist_every, double* hist_m, double* hist_logL, double* hist_pred,
     unsigned long long* n_evals)
 {
     __shared__ LayerTable T;
@@ -290,6 +290,8 @@ __global__ __launch_bounds__(64) void mh_steps_kernel(
             const size_t h = (size_t)((s + 1) / hist_every - 1);
             if (hist_m && lane < NP) hist_m[(h * B + ib) * NP + lane] = m[lane];
             if (hist_logL && lane == 0) hist_logL[h * B + ib] = logL;
+            if (hist_pred)
+                for (int k = lane; k < P; k += 64) hist_pred[(h * B + ib) * P + k] = pred[k];
         }
     }
 
@@ -375,7 +377,7 @@ int mhd_mh_steps(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t 
                  int32_t n_steps, const int32_t* idx, const double* cauchy, const double* u_acc,
                  double T, int32_t rotate, int32_t sample_prior, uint8_t* accepted,
                  int32_t* status, int32_t hist_every, double* hist_m, double* hist_logL,
-                 uint64_t* n_evals, void* stream)
+                 double* hist_pred, uint64_t* n_evals, void* stream)
 {
     if (int rc = check_problem(prob, true)) return rc;
     if (int rc = check_chains(chains, rotate)) return rc;
@@ -385,7 +387,7 @@ int mhd_mh_steps(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t 
     if (B == 0 || n_steps == 0) return MHD_OK;
     hipLaunchKernelGGL(mh_steps_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *prob, *chains,
                        B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior, accepted, status,
-                       hist_every, hist_m, hist_logL, (unsigned long long*)n_evals);
+                       hist_every, hist_m, hist_logL, hist_pred, (unsigned long long*)n_evals);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_mh_steps launch");
 }

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "../../include/mcmc_amd.h"
+#include "mhd_math.hpp"
 
 namespace mhd {
 
@@ -48,35 +49,49 @@ __device__ __forceinline__ int sgni(double x) { return (x > 0.0) - (x < 0.0); }
 // ---------------------------------------------------------------------------
 #pragma clang fp contract(fast)
 
-__device__ __forceinline__ void osc_or_evan(double k, double xk, double r, double arg,
-                                            double dpth, double& cs, double& over_r,
-                                            double& times_r, double& ex)
+// One wave type (P or S) in one layer.  Input: k, xk = omega/v, dpth.
+// Output: cs (cos or scaled cosh), over_r (sin/r or scaled sinh/r), times_r
+// (-r*sin or r*scaled sinh), em = exp(-r*dpth) when evanescent (1 otherwise),
+// ex = r*dpth when evanescent (0 otherwise).
+__device__ __forceinline__ void osc_or_evan(double k, double xk, double dpth, double& cs,
+                                            double& over_r, double& times_r, double& em,
+                                            double& ex)
 {
-    // cs = cos / cosh-like term, over_r = sin/r, times_r = -/+ r*sin, ex = exponent pulled out
+    const double s2 = (k + xk) * fabs(k - xk);
+    const double ir = rsqrt_pos(fmax(s2, 1.0e-300));
+    const double r = s2 * ir;
+    const double arg = r * dpth;
     if (k < xk) {
         double s, c;
-        sincos(arg, &s, &c);
+        if (arg < 1.0e5) sincos_pio2(arg, s, c); else sincos(arg, &s, &c);
         cs = c;
-        over_r = s / r;
+        over_r = s * ir;
         times_r = -r * s;
+        em = 1.0;
         ex = 0.0;
     } else if (k == xk) {
         cs = 1.0;
         over_r = dpth;
         times_r = 0.0;
+        em = 1.0;
         ex = 0.0;
     } else {
-        double fac = (arg < 16.0) ? exp(-2.0 * arg) : 0.0;
+        em = exp_neg(fmin(arg, 700.0));
+        const double fac = (arg < 16.0) ? em * em : 0.0;
         cs = (1.0 + fac) * 0.5;
-        double sh = (1.0 - fac) * 0.5;
-        over_r = sh / r;
+        const double sh = (1.0 - fac) * 0.5;
+        over_r = sh * ir;
         times_r = r * sh;
         ex = arg;
     }
 }
 
+// Rayleigh period equation (Dunkin compound matrix).  Returns the first
+// component of the propagated, rescaled vector; *scale_exp receives the sum of
+// the binary exponents taken out, so that value * 2^(*scale_exp) is the
+// unscaled (smooth) secular function up to one positive constant.
 __device__ __forceinline__ double secular_rayleigh(const LayerTable& T, double omega,
-                                                   double inv_om2, double c)
+                                                   double inv_om2, double c, int* scale_exp)
 {
     const int L = T.L;
     const double k = omega / c;
@@ -95,22 +110,20 @@ __device__ __forceinline__ double secular_rayleigh(const LayerTable& T, double o
     double e2 = rho1 * (gamm1 - gammk * ra * rb);
     double e3 = rho1 * rb;
     double e4 = k2 - ra * rb;
+    int sexp = 0;
 
     for (int m = L - 2; m >= 0; --m) {
         xka = omega * T.inv_a[m];
         xkb = omega * T.inv_b[m];
         gammk = T.twob2[m] * inv_om2;
         gam = gammk * k2;
-        ra = sqrt((k + xka) * fabs(k - xka));
-        rb = sqrt((k + xkb) * fabs(k - xkb));
         const double dpth = T.d[m];
         rho1 = T.rho[m];
         const double irho = T.inv_rho[m];
-        double cosp, w, x, pex, cosq, y, z, sex;
-        osc_or_evan(k, xka, ra, ra * dpth, dpth, cosp, w, x, pex);
-        osc_or_evan(k, xkb, rb, rb * dpth, dpth, cosq, y, z, sex);
-        const double exa = pex + sex;
-        const double a0 = (exa < 60.0) ? exp(-exa) : 0.0;
+        double cosp, w, x, ep, pex, cosq, y, z, eq, sex;
+        osc_or_evan(k, xka, dpth, cosp, w, x, ep, pex);
+        osc_or_evan(k, xkb, dpth, cosq, y, z, eq, sex);
+        const double a0 = (pex + sex < 60.0) ? ep * eq : 0.0;
         const double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w,
                      cqx = cosq * x, xy = x * y, xz = x * z, wy = w * y, wz = w * z;
         gamm1 = gam - 1.0;
@@ -144,13 +157,15 @@ __device__ __forceinline__ double secular_rayleigh(const LayerTable& T, double o
         const double n4 = e0 * ca04 + e1 * ca03 + e2 * ca24 + e3 * ca01 + e4 * ca00;
         // rescale by an exact power of two (sign-preserving, no rounding)
         const double t1 = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
-        const int ex = (t1 < 1.0e-40) ? 0 : -__builtin_amdgcn_frexp_exp(t1);
-        e0 = ldexp(n0, ex);
-        e1 = ldexp(n1, ex);
-        e2 = ldexp(n2, ex);
-        e3 = ldexp(n3, ex);
-        e4 = ldexp(n4, ex);
+        const int ex = (t1 < 1.0e-40) ? 0 : __builtin_amdgcn_frexp_exp(t1);
+        sexp += ex;
+        e0 = ldexp(n0, -ex);
+        e1 = ldexp(n1, -ex);
+        e2 = ldexp(n2, -ex);
+        e3 = ldexp(n3, -ex);
+        e4 = ldexp(n4, -ex);
     }
+    if (scale_exp) *scale_exp = sexp;
     return e0;
 }
 
@@ -166,10 +181,9 @@ __device__ __forceinline__ double secular_love(const LayerTable& T, double omega
     for (int m = L - 2; m >= 0; --m) {
         const double xmu = T.rho[m] * T.b[m] * T.b[m];
         xkb = omega * T.inv_b[m];
-        rb = sqrt((k + xkb) * fabs(k - xkb));
         const double dpth = T.d[m];
-        double cosq, y, z, sex;
-        osc_or_evan(k, xkb, rb, rb * dpth, dpth, cosq, y, z, sex);
+        double cosq, y, z, eq, sex;
+        osc_or_evan(k, xkb, dpth, cosq, y, z, eq, sex);
         const double e10 = e1 * cosq + e2 * xmu * z;
         const double e20 = e1 * y / xmu + e2 * cosq;
         const double xnor = fmax(fabs(e10), fabs(e20));
@@ -184,7 +198,7 @@ __device__ __forceinline__ double secular(const LayerTable& T, int wave, double 
 {
     omega = fmax(omega, 1.0e-4);
     if (wave == MHD_LOVE) return secular_love(T, omega, c);
-    return secular_rayleigh(T, omega, 1.0 / (omega * omega), c);
+    return secular_rayleigh(T, omega, 1.0 / (omega * omega), c, nullptr);
 }
 
 // ---------------------------------------------------------------------------

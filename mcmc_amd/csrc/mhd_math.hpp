@@ -1,0 +1,118 @@
+// mhd_math.hpp -- small FP64 elementary functions for the secular-function
+// kernels.  Written for straight-line VALU code on gfx950: no tables, no
+// divisions, no slow paths inside the argument ranges the kernels use.  The
+// same source compiles for the host (tests/test_math_host.py builds it with g++)
+// so accuracy is checked against libm without a GPU.
+//
+//   sincos_pio2(x, s, c)  |x| <= 1e5: three-constant Cody-Waite reduction by
+//                         pi/2 (exact products through fma) + the classic
+//                         degree-13 / degree-14 minimax kernels; < 1 ulp.
+//   exp_neg(y)            exp(-y) for 0 <= y <= 700: ln2 hi/lo reduction +
+//                         degree-13 polynomial + ldexp; < 1 ulp.
+//   rsqrt_pos(x)          1/sqrt(x), x > 0 normal: hardware seed (device) or
+//                         1/sqrt (host) refined by two Newton steps.
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#define MHD_HD __host__ __device__ __forceinline__
+#else
+#define MHD_HD inline
+#endif
+
+namespace mhd {
+
+MHD_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+MHD_HD void sincos_pio2(double x, double& s, double& c)
+{
+    // pi/2 = P1 + P2 + P3 (each the nearest double of the running remainder)
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double P1 = 1.57079632679489655800e+00;
+    const double P2 = 6.12323399573676603587e-17;
+    const double P3 = -1.49738490485916983294e-33;
+    const double kf = __builtin_rint(x * INV_PIO2);
+    double r = fma_(-kf, P1, x);
+    r = fma_(-kf, P2, r);
+    r = fma_(-kf, P3, r);
+    const int q = (int)kf;
+    const double z = r * r;
+    // sin kernel on [-pi/4, pi/4]
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double ps = fma_(z, S6, S5);
+    ps = fma_(z, ps, S4);
+    ps = fma_(z, ps, S3);
+    ps = fma_(z, ps, S2);
+    ps = fma_(z, ps, S1);
+    const double sr = fma_(r * z, ps, r);
+    // cos kernel
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double pc = fma_(z, C6, C5);
+    pc = fma_(z, pc, C4);
+    pc = fma_(z, pc, C3);
+    pc = fma_(z, pc, C2);
+    pc = fma_(z, pc, C1);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + z * z * pc);
+    // quadrant
+    const double ss = (q & 1) ? cr : sr;
+    const double cs = (q & 1) ? sr : cr;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cs : cs;
+}
+
+MHD_HD double exp_neg(double y)
+{
+    // exp(-y), 0 <= y <= 700
+    const double LOG2E = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double x = -y;
+    const double nf = __builtin_rint(x * LOG2E);
+    double r = fma_(-nf, LN2_HI, x);
+    r = fma_(-nf, LN2_LO, r);
+    // e^r, |r| <= ln2/2: Taylor to degree 13 (remainder < 5e-18)
+    double p = 1.0 / 6227020800.0;
+    p = fma_(p, r, 1.0 / 479001600.0);
+    p = fma_(p, r, 1.0 / 39916800.0);
+    p = fma_(p, r, 1.0 / 3628800.0);
+    p = fma_(p, r, 1.0 / 362880.0);
+    p = fma_(p, r, 1.0 / 40320.0);
+    p = fma_(p, r, 1.0 / 5040.0);
+    p = fma_(p, r, 1.0 / 720.0);
+    p = fma_(p, r, 1.0 / 120.0);
+    p = fma_(p, r, 1.0 / 24.0);
+    p = fma_(p, r, 1.0 / 6.0);
+    p = fma_(p, r, 0.5);
+    p = fma_(p, r, 1.0);
+    p = fma_(p, r, 1.0);
+    return __builtin_ldexp(p, (int)nf);
+}
+
+MHD_HD double rsqrt_pos(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+#else
+    double y = (double)(1.0f / __builtin_sqrtf((float)x));  // a seed of similar quality
+#endif
+    // y <- y + y*(1/2 - x*y*y/2) twice (quadratic convergence)
+    double h = 0.5 * y;
+    double e = fma_(-x * y, h, 0.5);
+    y = fma_(y, e, y);
+    h = 0.5 * y;
+    e = fma_(-x * y, h, 0.5);
+    y = fma_(y, e, y);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    h = 0.5 * y;  // the float seed is only 24 bits: one more step on the host
+    e = fma_(-x * y, h, 0.5);
+    y = fma_(y, e, y);
+#endif
+    return y;
+}
+
+}  // namespace mhd

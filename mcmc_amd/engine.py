@@ -157,7 +157,7 @@ class DeviceChains:
         return status
 
     def steps(self, idx, cauchy, u_acc, T=1.0, rotate=0, sample_prior=False, hist_every=0,
-              want_flags=True):
+              want_flags=True, want_pred_hist=False):
         """Run S = idx.shape[0] Metropolis-Hastings steps for every chain.
 
         idx [S,B] int32, cauchy [S,B], u_acc [S,B] are device tensors of host-supplied draws.
@@ -172,7 +172,7 @@ class DeviceChains:
         cauchy, u_acc = cauchy.contiguous(), u_acc.contiguous()
         dev = self.prob.device
         out = {}
-        acc = st = hm = hl = None
+        acc = st = hm = hl = hp = None
         if want_flags:
             acc = torch.empty((S, B), dtype=torch.uint8, device=dev)
             st = torch.empty((S, B), dtype=torch.int32, device=dev)
@@ -181,11 +181,16 @@ class DeviceChains:
             hm = torch.empty((S // hist_every, B, self.prob.NP), dtype=torch.float64, device=dev)
             hl = torch.empty((S // hist_every, B), dtype=torch.float64, device=dev)
             out["hist_m"], out["hist_logL"] = hm, hl
+            if want_pred_hist:
+                hp = torch.empty((S // hist_every, B, self.prob.P), dtype=torch.float64,
+                                 device=dev)
+                out["hist_pred"] = hp
         ch = self.struct()
         L.check(L.lib().mhd_mh_steps(
             ctypes.byref(self.prob.c), ctypes.byref(ch), B, S, _ptr(idx), _ptr(cauchy),
             _ptr(u_acc), float(T), int(rotate), int(bool(sample_prior)), _ptr(acc),
-            _ptr(st), int(hist_every), _ptr(hm), _ptr(hl), _ptr(self.n_evals), _stream()))
+            _ptr(st), int(hist_every), _ptr(hm), _ptr(hl), _ptr(hp), _ptr(self.n_evals),
+            _stream()))
         return out
 
     def cov_accumulate(self):
