@@ -104,11 +104,15 @@ def main():
     ap.add_argument("--chunk", type=int, default=250, help="MH steps per kernel launch")
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--search", type=int, default=2,
+                    help="2 = period-parallel root search (default), 1 = wave-sequential")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from mcmc_amd.engine import DeviceChains, DeviceProblem
+    from mcmc_amd import _lib as L
+    L.check(L.lib().mhd_set_search(args.search))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -195,7 +199,7 @@ def main():
                             "inversion, 1024 independent chains x 40 periods per GPU",
                 "chains_per_gpu": B, "n_periods": N_PERIODS, "n_layers": N_LAYERS,
                 "proposal": "cauchy", "likelihood": "normal", "rotation": "off",
-                "steps_per_launch": args.chunk, "acceptance_rate": round(acc_rate, 4),
+                "steps_per_launch": args.chunk, "search": args.search, "acceptance_rate": round(acc_rate, 4),
             },
             "roofline": {
                 "bound": "valu_fp64",

@@ -106,6 +106,14 @@ int mhd_abi_version(void);
 const char *mhd_last_error(void);
 
 /*
+ * Root-search algorithm used by the forward model, process-wide: 2 (default) =
+ * period-parallel search (predict, replay, verify), 1 = wave-sequential search.
+ * Both return the sequential algorithm's result bit for bit; this is a tuning
+ * and testing switch with no counterpart in the reference.
+ */
+int mhd_set_search(int32_t algorithm);
+
+/*
  * Secular (period-equation) function values, for diagnostics and parity gates:
  * delta[i] = Delta(c[i]) of chain chain[i] at period index period[i].
  * Replaces nothing the reference calls directly; it is disba's dltar4 / dltar1

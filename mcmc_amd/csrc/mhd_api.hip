@@ -6,12 +6,16 @@
 #include <cstring>
 
 #include "mhd_device.hpp"
+#include "mhd_search2.hpp"
 
 using namespace mhd;
 
 namespace {
 
 thread_local char g_err[256] = "";
+
+// 2 = period-parallel predicted search (default), 1 = wave-sequential search
+int g_search = 2;
 
 int fail(int code, const char* what)
 {
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(64) void secular_kernel(mhd_problem_t p, const doub
                                                      const double* c, int N, double* delta)
 {
     // one wave per query keeps the table code identical to the other kernels
-    __shared__ LayerTable T;
+    LayerTable& T = g_T;
     __shared__ double m[MAXNP];
     const int q = blockIdx.x;
     if (q >= N) return;
@@ -78,9 +82,9 @@ __global__ __launch_bounds__(64) void secular_kernel(mhd_problem_t p, const doub
 
 __global__ __launch_bounds__(64) void forward_kernel(mhd_problem_t p, const double* params, int B,
                                                      double* vel, int32_t* status,
-                                                     unsigned long long* n_evals)
+                                                     unsigned long long* n_evals, int search)
 {
-    __shared__ LayerTable T;
+    LayerTable& T = g_T;
     __shared__ double m[MAXNP];
     __shared__ double t[MAXP];
     __shared__ double out[MAXP];
@@ -93,7 +97,11 @@ __global__ __launch_bounds__(64) void forward_kernel(mhd_problem_t p, const doub
     __syncthreads();
     build_layer_table(T, m, p.n_layers, p.vpvs, lane);
     EvalCount cnt = {0, 0};
-    const int st = forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, out, scratch, cnt);
+    const int st = (search == 2)
+                       ? forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, out,
+                                           scratch, cnt)
+                       : forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, out, scratch,
+                                      cnt);
     __syncthreads();
     for (int k = lane; k < P; k += 64) vel[(size_t)ib * P + k] = (st == MHD_ST_OK) ? out[k] : 0.0;
     if (lane == 0) {
@@ -161,9 +169,9 @@ __global__ __launch_bounds__(64) void mh_steps_kernel(
     mhd_problem_t p, mhd_chains_t ch, int B, int S, const int32_t* idx, const double* cauchy,
     const double* u_acc, double Temp, int rotate, int sample_prior, uint8_t* accepted,
     int32_t* status, int hist_every, double* hist_m, double* hist_logL, double* hist_pred,
-    unsigned long long* n_evals)
+    unsigned long long* n_evals, int search)
 {
-    __shared__ LayerTable T;
+    LayerTable& T = g_T;
     __shared__ double m[MAXNP];     // current parameters
     __shared__ double mn[MAXNP];    // normalised current parameters
     __shared__ double test[MAXNP];  // proposal
@@ -193,7 +201,14 @@ __global__ __launch_bounds__(64) void mh_steps_kernel(
     const double beta = ch.beta ? ch.beta[ib] : 1.0;
     const double* R = (rotate & MHD_ROT_FRAME) ? ch.rot + (size_t)ib * NP * NP : nullptr;
     long long c_acc = 0, c_rej = 0, c_bnd = 0, c_fm = 0;
+#ifdef MHD_PROFILE
+    const long long k_t0 = clock64(), k_w0 = wall_clock64();
+    if (lane == 0 && ib < 2048) g_times[2 * ib] = (unsigned long long)k_w0;
+#endif
     EvalCount cnt = {0, 0};
+    // a chain whose curves keep defeating the predictor (densely spaced modes) uses the
+    // wave-sequential search for a while, then tries the predictor again
+    int penalty = 0;
     __syncthreads();
 
     for (int s = 0; s < S; ++s) {
@@ -250,7 +265,15 @@ __global__ __launch_bounds__(64) void mh_steps_kernel(
         int st = (__ballot(!inb) != 0ull) ? MHD_ST_BOUNDS : MHD_ST_OK;
         if (st == MHD_ST_OK && !sample_prior) {
             build_layer_table(T, test, nl, p.vpvs, lane);
-            st = forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred, scratch, cnt);
+            if (search == 2 && penalty == 0) {
+                st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred,
+                                       scratch, cnt);
+                if (__builtin_amdgcn_readfirstlane(g_PS.trouble) >= 2) penalty = 8;
+            } else {
+                st = forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred, scratch,
+                                  cnt);
+                if (penalty > 0) --penalty;
+            }
             __syncthreads();
         }
         int acc = 0;
@@ -295,6 +318,13 @@ __global__ __launch_bounds__(64) void mh_steps_kernel(
         }
     }
 
+#ifdef MHD_PROFILE
+    if (lane == 0) {
+        atomicAdd(&g_prof[9], (unsigned long long)(clock64() - k_t0));
+        atomicAdd(&g_prof[10], (unsigned long long)(wall_clock64() - k_w0));
+        if (ib < 2048) g_times[2 * ib + 1] = (unsigned long long)wall_clock64();
+    }
+#endif
     if (lane < NP) ch.m[(size_t)ib * NP + lane] = m[lane];
     for (int k = lane; k < P; k += 64) ch.pred[(size_t)ib * P + k] = pred[k];
     if (lane == 0) {
@@ -320,6 +350,45 @@ extern "C" {
 
 int mhd_abi_version(void) { return MHD_ABI_VERSION; }
 
+// Resident workgroups per CU of the two main kernels (diagnostic).
+int mhd_debug_occupancy(int* mh_blocks, int* fwd_blocks)
+{
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(mh_blocks, mh_steps_kernel, 64, 0);
+    if (e != hipSuccess) return hip_fail(e, "occupancy");
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(fwd_blocks, forward_kernel, 64, 0);
+    return e == hipSuccess ? MHD_OK : hip_fail(e, "occupancy");
+}
+
+#ifdef MHD_PROFILE
+int mhd_debug_blk(unsigned long long* out8192, int reset)
+{
+    hipDeviceSynchronize();
+    if (out8192) hipMemcpyFromSymbol(out8192, HIP_SYMBOL(g_blk), 8192 * sizeof(unsigned long long));
+    if (reset) { static unsigned long long z[8192]; hipMemcpyToSymbol(HIP_SYMBOL(g_blk), z, sizeof(z)); }
+    return 0;
+}
+int mhd_debug_times(unsigned long long* out4096)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_times), 4096 * sizeof(unsigned long long));
+    return 0;
+}
+int mhd_debug_profile(unsigned long long* out16, int reset)
+{
+    hipDeviceSynchronize();
+    if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
+int mhd_set_search(int32_t algorithm)
+{
+    if (algorithm != 1 && algorithm != 2) return fail(MHD_EINVAL, "algorithm must be 1 or 2");
+    g_search = algorithm;
+    return MHD_OK;
+}
+
 const char* mhd_last_error(void) { return g_err; }
 
 int mhd_secular_batch(const mhd_problem_t* prob, const double* params, int32_t B,
@@ -344,7 +413,7 @@ int mhd_forward_batch(const mhd_problem_t* prob, const double* params, int32_t B
     if (B < 0) return fail(MHD_EINVAL, "negative batch");
     if (B == 0) return MHD_OK;
     hipLaunchKernelGGL(forward_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *prob, params, B,
-                       vel, status, (unsigned long long*)n_evals);
+                       vel, status, (unsigned long long*)n_evals, g_search);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_forward_batch launch");
 }
@@ -387,7 +456,8 @@ int mhd_mh_steps(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t 
     if (B == 0 || n_steps == 0) return MHD_OK;
     hipLaunchKernelGGL(mh_steps_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *prob, *chains,
                        B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior, accepted, status,
-                       hist_every, hist_m, hist_logL, hist_pred, (unsigned long long*)n_evals);
+                       hist_every, hist_m, hist_logL, hist_pred, (unsigned long long*)n_evals,
+                       g_search);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_mh_steps launch");
 }

@@ -42,7 +42,24 @@ struct LayerTable {
     int L;
 };
 
+// The layer table of the chain this workgroup works on.  File scope so that the one
+// out-of-line secular-function body reads it with LDS instructions, not through a pointer.
+__shared__ LayerTable g_T;
+
 __device__ __forceinline__ int sgni(double x) { return (x > 0.0) - (x < 0.0); }
+
+// A condition that is the same in every lane, made visible as such: the branch on it is a
+// scalar branch instead of an exec-masked region.
+__device__ __forceinline__ bool uni(bool c) { return __ballot(c) != 0ull; }
+
+// A double that is the same in every lane, moved to scalar registers.
+__device__ __forceinline__ double uniform_value(double x)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 // ---------------------------------------------------------------------------
 // Secular functions.  Only the sign of the result steers the search.
@@ -112,6 +129,7 @@ __device__ __forceinline__ double secular_rayleigh(const LayerTable& T, double o
     double e4 = k2 - ra * rb;
     int sexp = 0;
 
+#pragma nounroll
     for (int m = L - 2; m >= 0; --m) {
         xka = omega * T.inv_a[m];
         xkb = omega * T.inv_b[m];
@@ -169,7 +187,8 @@ __device__ __forceinline__ double secular_rayleigh(const LayerTable& T, double o
     return e0;
 }
 
-__device__ __forceinline__ double secular_love(const LayerTable& T, double omega, double c)
+__device__ __forceinline__ double secular_love(const LayerTable& T, double omega, double c,
+                                               int* scale_exp)
 {
     const int L = T.L;
     const double k = omega / c;
@@ -178,6 +197,8 @@ __device__ __forceinline__ double secular_love(const LayerTable& T, double omega
     double rb = sqrt((k + xkb) * fabs(k - xkb));
     double e1 = T.rho[h] * rb;
     double e2 = T.inv_b[h] * T.inv_b[h];
+    int sexp = 0;
+#pragma nounroll
     for (int m = L - 2; m >= 0; --m) {
         const double xmu = T.rho[m] * T.b[m] * T.b[m];
         xkb = omega * T.inv_b[m];
@@ -187,18 +208,46 @@ __device__ __forceinline__ double secular_love(const LayerTable& T, double omega
         const double e10 = e1 * cosq + e2 * xmu * z;
         const double e20 = e1 * y / xmu + e2 * cosq;
         const double xnor = fmax(fabs(e10), fabs(e20));
-        const int ex = (xnor < 1.0e-40) ? 0 : -__builtin_amdgcn_frexp_exp(xnor);
-        e1 = ldexp(e10, ex);
-        e2 = ldexp(e20, ex);
+        const int ex = (xnor < 1.0e-40) ? 0 : __builtin_amdgcn_frexp_exp(xnor);
+        sexp += ex;
+        e1 = ldexp(e10, -ex);
+        e2 = ldexp(e20, -ex);
     }
+    if (scale_exp) *scale_exp = sexp;
     return e1;
 }
 
-__device__ __forceinline__ double secular(const LayerTable& T, int wave, double omega, double c)
+struct SecVal {
+    double m;  // value after rescaling
+    int e;     // binary exponent taken out: m * 2^e is smooth in c
+};
+
+// The ONE out-of-line body of the period equation (keeps the kernels within the
+// instruction cache: every search stage calls this instead of inlining a copy).
+__device__ __attribute__((noinline)) SecVal eval_secular(int wave, double omega, double c)
 {
+    SecVal v;
     omega = fmax(omega, 1.0e-4);
-    if (wave == MHD_LOVE) return secular_love(T, omega, c);
-    return secular_rayleigh(T, omega, 1.0 / (omega * omega), c, nullptr);
+    if (wave == MHD_LOVE)
+        v.m = secular_love(g_T, omega, c, &v.e);
+    else
+        v.m = secular_rayleigh(g_T, omega, 1.0 / (omega * omega), c, &v.e);
+    return v;
+}
+
+__device__ __forceinline__ double secular(const LayerTable&, int wave, double omega, double c)
+{
+    return eval_secular(wave, omega, c).m;
+}
+
+// Value with its binary scale: value * 2^(*scale_exp) is a smooth function of c whose roots
+// are the roots of the period equation (used by the root predictor, which interpolates).
+__device__ __forceinline__ double secular_tracked(const LayerTable&, int wave, double omega,
+                                                  double c, int* scale_exp)
+{
+    const SecVal v = eval_secular(wave, omega, c);
+    *scale_exp = v.e;
+    return v.m;
 }
 
 // ---------------------------------------------------------------------------
@@ -282,6 +331,12 @@ struct EvalCount {
     unsigned long long exec;  // evaluations executed by lanes
 };
 
+__device__ __forceinline__ int mask_bit_sign(unsigned long long neg, unsigned long long pos,
+                                             int bit)
+{
+    return (int)((pos >> bit) & 1) - (int)((neg >> bit) & 1);
+}
+
 // One advance of the sequential scan: from (c1, idir) to the next abscissa c2.
 __device__ __forceinline__ double scan_next(double& c1, int& idir, double clow, double dc)
 {
@@ -300,7 +355,13 @@ __device__ __forceinline__ double scan_next(double& c1, int& idir, double clow, 
 
 // Bracket and refine one period (getsol), one wave.  All arguments are
 // wave-uniform.  s1st carries sign(del1st) between periods.  Returns success.
-__device__ inline bool solve_period_wave(const LayerTable& T, int wave, double t1, double& c1io,
+//
+// Round 1 evaluates the first 8 scan abscissae (lanes 0..7) and, for each of the 7
+// cells between them, the 7 nodes of a 3-level midpoint tree (lanes 8..56): when the
+// sign change lies in one of those cells -- the usual case -- three halvings are
+// already done.  Further rounds evaluate 64 scan abscissae, or the 63 nodes of a
+// 6-level tree.
+__device__ __attribute__((noinline)) bool solve_period_wave(const LayerTable& T, int wave, double t1, double& c1io,
                                          double clow, double dc, double cm, double betmx,
                                          bool ifirst, int& s1st, EvalCount& cnt)
 {
@@ -309,33 +370,80 @@ __device__ inline bool solve_period_wave(const LayerTable& T, int wave, double t
     double c1 = c1io, c2 = c1io;
     int idir = +1, s1 = 0, s2 = 0;
     bool have1 = false, bracketed = false;
+    int pre_levels = 0;               // halving levels already evaluated for the bracket
+    unsigned long long pneg = 0, ppos = 0;
+    int pbase = 0;                    // first lane of the bracket's 3-level tree
 
-    // ---- scan ----
+    // ---- round 1: 8 scan abscissae + 7 small trees (upward scan assumed) ----
+    {
+        // scan abscissa j (0..7) of the upward sequence
+        double q1 = c1, pt = c1;
+        int qd = +1;
+        const int jmine = (lane < 8) ? lane : (lane - 8) / 7 + 1;  // right end of my cell
+        double left = c1;
+        for (int i = 0; i < jmine; ++i) {
+            left = pt;
+            pt = scan_next(q1, qd, clow, dc);
+            // scan_next may move the left end to clow (reflection): the sequential code
+            // brackets between its current c1 and the new abscissa
+            left = q1;
+            q1 = pt;
+        }
+        double x = pt;
+        if (lane >= 8 && lane < 57) {
+            const int node = (lane - 8) % 7 + 1;  // 1..7, heap order
+            double a = left, b = pt;
+            const int depth = 31 - __clz(node);
+            for (int lvl = depth - 1; lvl >= 0; --lvl) {
+                const double mid = 0.5 * (a + b);
+                if ((node >> lvl) & 1) a = mid; else b = mid;
+            }
+            x = 0.5 * (a + b);
+        }
+        const bool act = lane < 57;
+        double del = 0.0;
+        if (act) del = secular(T, wave, omega, x);
+        const unsigned long long neg = __ballot(act && del < 0.0), pos = __ballot(act && del > 0.0);
+        cnt.exec += 57;
+        s1 = mask_bit_sign(neg, pos, 0);
+        cnt.lit += 1;
+        have1 = true;
+        if (ifirst) s1st = s1;
+        idir = (ifirst || s1st * s1 >= 0) ? +1 : -1;
+        if (idir > 0) {
+            for (int j = 1; j < 8; ++j) {
+                c2 = scan_next(c1, idir, clow, dc);
+                s2 = mask_bit_sign(neg, pos, j);
+                cnt.lit += 1;
+                if (s1 != s2) {
+                    bracketed = true;
+                    pre_levels = 3;
+                    pneg = neg;
+                    ppos = pos;
+                    pbase = 8 + (j - 1) * 7;
+                    break;
+                }
+                c1 = c2;
+                s1 = s2;
+                if (uni(c1 < cm || c1 >= betmx + dc)) return false;
+            }
+        }
+    }
+
+    // ---- scan on, 64 abscissae per round ----
     while (!bracketed) {
-        // lane j evaluates the abscissa the scan reaches after (have1 ? j+1 : j) advances
         double pc1 = c1, pt = c1;
         int pdir = idir;
-        const int nadv = have1 ? lane + 1 : lane;
-        for (int i = 0; i < nadv; ++i) {
+        for (int i = 0; i <= lane; ++i) {
             pt = scan_next(pc1, pdir, clow, dc);
             pc1 = pt;
         }
         const double del = secular(T, wave, omega, pt);
         const unsigned long long neg = __ballot(del < 0.0), pos = __ballot(del > 0.0);
         cnt.exec += 64;
-        int j = 0;
-        if (!have1) {
-            s1 = (int)((pos >> 0) & 1) - (int)((neg >> 0) & 1);
-            cnt.lit += 1;
-            have1 = true;
-            if (ifirst) s1st = s1;
-            idir = (ifirst || s1st * s1 >= 0) ? +1 : -1;
-            if (idir < 0) continue;  // speculated upward: evaluate the downward sequence
-            j = 1;
-        }
-        for (; j < 64; ++j) {
+        for (int j = 0; j < 64; ++j) {
             c2 = scan_next(c1, idir, clow, dc);
-            s2 = (int)((pos >> j) & 1) - (int)((neg >> j) & 1);
+            s2 = mask_bit_sign(neg, pos, j);
             cnt.lit += 1;
             if (s1 != s2) {
                 bracketed = true;
@@ -343,14 +451,35 @@ __device__ inline bool solve_period_wave(const LayerTable& T, int wave, double t
             }
             c1 = c2;
             s1 = s2;
-            if (c1 < cm || c1 >= betmx + dc) return false;
+            if (uni(c1 < cm || c1 >= betmx + dc)) return false;
         }
     }
 
-    // ---- refine: pure interval halving, 6 levels of midpoints per batch ----
+    // ---- refine: pure interval halving ----
     double c3 = 0.0;
     int nctrl = 2;
     bool done = false;
+    if (pre_levels) {
+        int node = 1;
+        while (node < 8) {
+            c3 = 0.5 * (c1 + c2);
+            const int s3 = mask_bit_sign(pneg, ppos, pbase + node - 1);
+            cnt.lit += 1;
+            if (s3 * s1 < 0) {
+                c2 = c3;
+                node = 2 * node;
+            } else {
+                c1 = c3;
+                s1 = s3;
+                node = 2 * node + 1;
+            }
+            if (uni(fabs(c1 - c2) <= 1.0e-6 * c1)) {
+                done = true;
+                break;
+            }
+            ++nctrl;
+        }
+    }
     while (!done) {
         double a = c1, b = c2;
         const int t = lane ? lane : 1;
@@ -366,7 +495,7 @@ __device__ inline bool solve_period_wave(const LayerTable& T, int wave, double t
         int node = 1;
         while (node < 64) {
             c3 = 0.5 * (c1 + c2);
-            const int s3 = (int)((pos >> node) & 1) - (int)((neg >> node) & 1);
+            const int s3 = mask_bit_sign(neg, pos, node);
             cnt.lit += 1;
             // the sequential loop applies at most 98 updates; the 99th midpoint is
             // evaluated and returned without being applied
@@ -382,7 +511,7 @@ __device__ inline bool solve_period_wave(const LayerTable& T, int wave, double t
                 s1 = s3;
                 node = 2 * node + 1;
             }
-            if (fabs(c1 - c2) <= 1.0e-6 * c1) {
+            if (uni(fabs(c1 - c2) <= 1.0e-6 * c1)) {
                 done = true;
                 break;
             }
@@ -390,24 +519,25 @@ __device__ inline bool solve_period_wave(const LayerTable& T, int wave, double t
         }
     }
     c1io = c3;
-    return c3 <= betmx;
+    return uni(c3 <= betmx);
 }
 
 // One phase-velocity curve (getc) for the table in T; t[] ascending periods,
 // c[] in LDS.  Wave-uniform.  Returns MHD_ST_OK or MHD_ST_NOROOT.
-__device__ inline int phase_curve_wave(const LayerTable& T, int wave, const double* t, int P,
+// kstart > 0 resumes the fundamental mode at period kstart: c[0..kstart-1] and
+// the sign of the first secular value of period 0 (s1st) are then inputs.
+__device__ __attribute__((noinline)) int phase_curve_wave(const LayerTable& T, int wave, const double* t, int P,
                                        double tscale, int mode, double dc, double* c,
-                                       EvalCount& cnt)
+                                       EvalCount& cnt, int kstart = 0, int s1st = 0)
 {
     if (T.b[0] <= 0.0) return MHD_ST_NOROOT;  // water layer: not part of this workload
     const double cc = T.cc, betmx = T.betmx, cm = T.cc;
     dc = fabs(dc);
     const double one = 1.0e-2, onea = 1.5;
     double c1 = cc, clow = cc;
-    int s1st = 0;
-    for (int k = 0; k < P; ++k) c[k] = 0.0;
+    for (int k = kstart; k < P; ++k) c[k] = 0.0;
     for (int iq = 0; iq <= mode; ++iq) {
-        for (int k = 0; k < P; ++k) {
+        for (int k = (iq == 0 ? kstart : 0); k < P; ++k) {
             const bool ifirst = (k == 0);
             if (ifirst && iq == 0) {
                 clow = cc;

@@ -1,0 +1,557 @@
+// mhd_search2.hpp -- period-parallel dispersion curve (fundamental mode, phase).
+//
+// The sequential search couples the periods only through the abscissa lattice:
+// period k starts at c[k-1] - 1.5*dc.  Which lattice points it visits depends on
+// c[k-1] exactly, but the SIGN it sees at any point follows from where the root
+// of period k lies.  So the curve is computed in four stages, one wave per chain:
+//
+//   1. predict_coarse: walk the periods in order, several at a time; the 64
+//      lanes evaluate windows of dc-spaced abscissae for the next 1..8 periods
+//      and bracket each period's root to one dc cell (continuation in period,
+//      like the sequential search, but on approximate grids and without halving).
+//   2. predict_refine: one lane per period tightens its bracket to 1e-10 relative
+//      with the Illinois method on the exponent-tracked (smooth) secular value.
+//   3. replay: the sequential algorithm is executed with signs inferred from the
+//      brackets; no evaluations (a point that falls inside a bracket is really
+//      evaluated).  Every abscissa it consumes is recorded.
+//   4. verify: the lanes really evaluate every recorded abscissa.  If all signs
+//      agree, the replay WAS the sequential algorithm, bit for bit.  At the first
+//      disagreement the periods before it are exact and the rest of the curve is
+//      recomputed by the wave-sequential search of mhd_device.hpp.
+//
+// Stages 1-2 are only a predictor: any failure there costs time, never accuracy.
+#pragma once
+#include "mhd_device.hpp"
+
+namespace mhd {
+
+constexpr int NPTS = 1536;
+
+struct PredictScratch {
+    double lo[MAXP], hi[MAXP];    // root bracket per period (stage 1: one dc cell)
+    double fam[MAXP], fbm[MAXP];  // tracked values at the bracket ends: mantissa ...
+    int fae[MAXP], fbe[MAXP];     // ... and binary exponent
+    signed char slo[MAXP], shi[MAXP];
+    double fm[64];  // lane values of the current stage-1 round
+    int fe[64];
+    double px[NPTS];         // abscissae consumed by the replay
+    unsigned char pk[NPTS];  // their period
+    signed char ps[NPTS];    // the sign the replay inferred there
+    unsigned short plit[MAXP];  // evaluations the sequential algorithm spends on the period
+    int trouble;  // repairs the last predicted curve needed (9: the predictor gave up)
+};
+
+__shared__ PredictScratch g_PS;
+
+#pragma clang fp contract(off)
+
+#ifdef MHD_PROFILE
+__device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_times[4096];
+__device__ unsigned long long g_blk[1024 * 8];
+#define PROF_T0 long long _t0 = clock64();
+#define PROF_ADD(i) { long long _t1 = clock64(); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_prof[i], (unsigned long long)(_t1 - _t0)); if (blockIdx.x < 1024) g_blk[blockIdx.x * 8 + i] += (unsigned long long)(_t1 - _t0); } _t0 = _t1; }
+#else
+#define PROF_T0
+#define PROF_ADD(i)
+#endif
+
+__device__ __forceinline__ int mask_sign(unsigned long long neg, unsigned long long pos, int bit)
+{
+    return (int)((pos >> bit) & 1) - (int)((neg >> bit) & 1);
+}
+
+// ---- stage 1 ----------------------------------------------------------------
+// Brackets the roots of periods kbeg..n-1 to one dc cell each and returns n (= P normally);
+// kbeg > 0 continues from the root rprev_in of period kbeg-1 (sigma0_in = sign of the secular
+// function of period 0 at the floor).
+// n < P: period n-1 has no sign change below the ceiling (its bracket is "constant sign"),
+// the sequential search fails there.  -1: give up (the caller uses the sequential search).
+__device__ __attribute__((noinline)) int predict_coarse(int wave, const double* t, int kbeg,
+                                                        int P, double tscale, double dc,
+                                                        double rprev_in, int sigma0_in,
+                                                        EvalCount& cnt)
+{
+    PredictScratch& S = g_PS;
+    const int lane = threadIdx.x & 63;
+    const double cc = g_T.cc, top = g_T.betmx + dc;
+    int k0 = kbeg, sigma0 = sigma0_in, carry_sign = 0, rounds = 0;
+    double rprev = rprev_in, inc = 1.0, carry_base = 0.0;
+    bool have_inc = false, carry = false;
+
+    while (k0 < P) {
+        if (++rounds > 96) return -1;
+        int lg = 0;  // log2 of the number of periods in this round
+        if (!(k0 == 0 || carry)) {
+            const double ai = fabs(inc);
+            lg = !have_inc ? 2 : (ai <= 2.0 ? 3 : (ai <= 5.0 ? 2 : (ai <= 12.0 ? 1 : 0)));
+        }
+        const int g = 1 << lg, W = 64 >> lg;
+        const int gact = (P - k0 < g) ? P - k0 : g;
+        // window bases are fixed before the round's evaluations (frozen copies)
+        const double pinc0 = have_inc ? inc : 1.0, rprev0 = rprev, cbase0 = carry_base;
+        const bool carry0 = carry;
+        const int kfirst = k0;
+        auto base_of = [&](int q) -> double {
+            if (carry0 && q == 0) return cbase0;
+            if (kfirst + q == 0) return cc;
+            const double pstart = rprev0 + q * pinc0 * dc - 1.5 * dc;
+            int mlo = (q == 0) ? 0 : (1 + (q + 1) / 2);
+            if (W >= 16) mlo *= 2;
+            double b = pstart - mlo * dc;
+            if (b < cc - 2.0 * dc) b = cc - 2.0 * dc;
+            return b;
+        };
+        const int jj = lane >> (6 - lg), j = lane & (W - 1);
+        const bool active = jj < gact;
+        SecVal v = {0.0, 0};
+        if (active) {
+            const double omega = TWOPI / (t[k0 + jj] / tscale);
+            v = eval_secular(wave, omega, base_of(jj) + j * dc);
+        }
+        const unsigned long long neg = __ballot(active && v.m < 0.0);
+        const unsigned long long pos = __ballot(active && v.m > 0.0);
+        __syncthreads();
+        S.fm[lane] = v.m;
+        S.fe[lane] = v.e;
+        __syncthreads();
+        cnt.exec += (unsigned long long)(gact * W);
+        if (k0 == 0 && !carry) sigma0 = mask_sign(neg, pos, 0);
+
+        int resolved = 0;
+        bool carried_now = false;
+        for (int q = 0; q < gact; ++q) {
+            const int k = k0 + q, bit0 = q * W;
+            const double s = base_of(q);
+            int start, s1;
+            if (carry && q == 0) {
+                start = -1;
+                s1 = carry_sign;
+            } else if (k == 0) {
+                start = 0;
+                s1 = mask_sign(neg, pos, bit0);
+            } else {
+                const double st = rprev - 1.5 * dc;
+                const double off = (st - s) / dc;
+                if (off < -1.0e-9) break;
+                start = (int)floor(off + 1.0e-9);
+                if (start >= W - 1) break;
+                s1 = mask_sign(neg, pos, bit0 + start);
+                if (s1 * sigma0 < 0) {
+                    // reversed dispersion: the root lies below the start
+                    int j2 = start - 1;
+                    for (; j2 >= 0; --j2)
+                        if (mask_sign(neg, pos, bit0 + j2) != s1) break;
+                    if (j2 >= 0) {
+                        S.lo[k] = s + j2 * dc;
+                        S.fam[k] = S.fm[bit0 + j2];
+                        S.fae[k] = S.fe[bit0 + j2];
+                        S.hi[k] = s + (j2 + 1) * dc;
+                        S.fbm[k] = S.fm[bit0 + j2 + 1];
+                        S.fbe[k] = S.fe[bit0 + j2 + 1];
+                        const double nr = s + (j2 + 0.5) * dc;
+                        inc = (nr - rprev) / dc;
+                        have_inc = true;
+                        rprev = nr;
+                        ++resolved;
+                        continue;
+                    }
+                    if (resolved > 0) break;
+                    // its own round: 64 abscissae downwards from the start
+                    if (++rounds > 96) return -1;
+                    const double xd = st - lane * dc;
+                    const bool act = xd > cc;
+                    SecVal vd = {0.0, 0};
+                    if (act) vd = eval_secular(wave, TWOPI / (t[k] / tscale), xd);
+                    const unsigned long long ng = __ballot(act && vd.m < 0.0);
+                    const unsigned long long ps = __ballot(act && vd.m > 0.0);
+                    const unsigned long long am = __ballot(act);
+                    __syncthreads();
+                    S.fm[lane] = vd.m;
+                    S.fe[lane] = vd.e;
+                    __syncthreads();
+                    cnt.exec += (unsigned long long)__popcll(am);
+                    const int sd = mask_sign(ng, ps, 0);
+                    int j3 = 1;
+                    for (; j3 < 64; ++j3) {
+                        if (!((am >> j3) & 1)) return -1;  // reached the floor
+                        if (mask_sign(ng, ps, j3) != sd) break;
+                    }
+                    if (j3 >= 64) return -1;
+                    S.lo[k] = st - j3 * dc;
+                    S.fam[k] = S.fm[j3];
+                    S.fae[k] = S.fe[j3];
+                    S.hi[k] = st - (j3 - 1) * dc;
+                    S.fbm[k] = S.fm[j3 - 1];
+                    S.fbe[k] = S.fe[j3 - 1];
+                    const double nr = st - (j3 - 0.5) * dc;
+                    inc = (nr - rprev) / dc;
+                    have_inc = true;
+                    rprev = nr;
+                    ++resolved;
+                    break;
+                }
+            }
+            int jn = start + 1;
+            bool got = false;
+            for (; jn < W; ++jn) {
+                if (mask_sign(neg, pos, bit0 + jn) != s1) {
+                    got = true;
+                    break;
+                }
+                if (s + jn * dc >= top) {
+                    // no sign change below the ceiling: the sequential search fails here
+                    S.lo[k] = 1.0e300;
+                    S.hi[k] = 1.0e301;
+                    S.fam[k] = (double)s1;
+                    S.fbm[k] = (double)s1;
+                    S.fae[k] = 0;
+                    S.fbe[k] = 0;
+                    __syncthreads();
+                    return k + 1;
+                }
+            }
+            if (!got) {
+                if (q > 0) break;  // next round gives this period its own windows
+                carry = true;
+                carried_now = true;
+                carry_base = s + W * dc;
+                carry_sign = s1;
+                S.lo[k] = s + (W - 1) * dc;
+                S.fam[k] = S.fm[bit0 + W - 1];
+                S.fae[k] = S.fe[bit0 + W - 1];
+                break;
+            }
+            if (jn - 1 >= 0) {
+                S.lo[k] = s + (jn - 1) * dc;
+                S.fam[k] = S.fm[bit0 + jn - 1];
+                S.fae[k] = S.fe[bit0 + jn - 1];
+            }
+            S.hi[k] = s + jn * dc;
+            S.fbm[k] = S.fm[bit0 + jn];
+            S.fbe[k] = S.fe[bit0 + jn];
+            const double nr = s + (jn - 0.5) * dc;
+            if (k > 0) {
+                inc = (nr - rprev) / dc;
+                have_inc = true;
+            }
+            rprev = nr;
+            ++resolved;
+            carry = false;
+        }
+        k0 += resolved;
+        if (resolved == 0 && !carried_now) {
+            if (g == 1) return -1;
+            inc = (fabs(inc) + 1.0) * 4.0;  // widen the windows
+        }
+    }
+    __syncthreads();
+    return P;
+}
+
+// ---- stage 2 ----------------------------------------------------------------
+__device__ __attribute__((noinline)) void predict_refine(int wave, const double* t, int kbeg,
+                                                         int P, double tscale, EvalCount& cnt)
+{
+    PredictScratch& S = g_PS;
+    const int lane = threadIdx.x & 63;
+    for (int kb = kbeg; kb < P; kb += 64) {
+        const int k = kb + lane;
+        const bool active = k < P;
+        double a = 1.0, b = 1.0, fa = 1.0, fb = -1.0, omega = 1.0;
+        int ea = 0, eb = 0;
+        if (active) {
+            a = S.lo[k];
+            b = S.hi[k];
+            fa = S.fam[k];
+            fb = S.fbm[k];
+            ea = S.fae[k];
+            eb = S.fbe[k];
+            omega = TWOPI / (t[k] / tscale);
+        }
+        const int sa = sgni(fa);
+        int sb = sgni(fb);
+        bool done = !active || sa == sb || sa == 0 || sb == 0;
+        int side = 0;
+        for (int it = 0; it < 48; ++it) {
+            const double tol = 1.0e-10 * a;
+            if (b - a <= tol) done = true;
+            const unsigned long long todo = __ballot(!done);
+            if (todo == 0ull) break;
+            cnt.exec += (unsigned long long)__popcll(todo);
+            if (!done) {
+                int de = eb - ea;
+                de = de > 1000 ? 1000 : (de < -1000 ? -1000 : de);
+                const double rho = ldexp(fb / fa, de);  // < 0
+                double x = a + (b - a) / (1.0 - rho);
+                const double w = b - a;
+                const double mgn = fmax(0.25 * tol, 1.0e-3 * w);
+                if (!(x > a + mgn)) x = a + mgn;
+                if (!(x < b - mgn)) x = b - mgn;
+                const SecVal v = eval_secular(wave, omega, x);
+                if (sgni(v.m) == sa) {
+                    a = x;
+                    fa = v.m;
+                    ea = v.e;
+                    if (side == -1) fb *= 0.5;
+                    side = -1;
+                } else {
+                    b = x;
+                    fb = v.m;
+                    eb = v.e;
+                    sb = sgni(v.m);
+                    if (side == +1) fa *= 0.5;
+                    side = +1;
+                }
+            }
+        }
+        if (active) {
+            S.lo[k] = a;
+            S.hi[k] = b;
+            S.slo[k] = (signed char)sa;
+            S.shi[k] = (signed char)sb;
+        }
+    }
+    __syncthreads();
+}
+
+// ---- stage 3 ----------------------------------------------------------------
+struct Bracket {
+    double lo, hi;
+    int slo, shi;
+};
+
+// Sign of the secular function of period k at x: inferred from the bracket, or really
+// evaluated (by every lane, the result is uniform) when x falls inside the bracket.
+__device__ __forceinline__ int replay_sign(int wave, int k, double omega, double x, Bracket& br,
+                                           int& npts, int& nlit, unsigned long long& nexec)
+{
+    ++nlit;
+    int s;
+    if (uni(x <= br.lo)) {
+        s = br.slo;
+    } else if (uni(x >= br.hi)) {
+        s = br.shi;
+    } else {
+        s = __builtin_amdgcn_readfirstlane(sgni(eval_secular(wave, omega, x).m));
+        nexec += 1;
+        if (s == br.slo) br.lo = x; else br.hi = x;
+        return s;
+    }
+    if (npts < NPTS) {  // every lane stores the same values
+        g_PS.px[npts] = x;
+        g_PS.pk[npts] = (unsigned char)k;
+        g_PS.ps[npts] = (signed char)s;
+    }
+    ++npts;  // beyond NPTS: overflow, detected by the caller
+    return s;
+}
+
+// getsol with inferred signs (same control flow and abscissa arithmetic as
+// solve_period_wave).  Every value here is the same in all lanes.
+__device__ __forceinline__ bool replay_period(int wave, int k, double t1, double& c1io,
+                                              double clow, double dc, double cm, double betmx,
+                                              bool ifirst, int& s1st, int& npts, int& nlit,
+                                              unsigned long long& nexec)
+{
+    Bracket br = {uniform_value(g_PS.lo[k]), uniform_value(g_PS.hi[k]),
+                  __builtin_amdgcn_readfirstlane((int)g_PS.slo[k]),
+                  __builtin_amdgcn_readfirstlane((int)g_PS.shi[k])};
+    const double omega = TWOPI / t1;
+    double c1 = c1io, c2;
+    int s1 = replay_sign(wave, k, omega, c1, br, npts, nlit, nexec);
+    if (ifirst) s1st = s1;
+    int idir = (ifirst || s1st * s1 >= 0) ? +1 : -1;
+    for (;;) {
+        if (npts > NPTS) return false;
+        // one advance of the scan (scan_next with scalar branches)
+        for (;;) {
+            c2 = (idir > 0) ? c1 + dc : c1 - dc;
+            if (uni(c2 <= clow)) {
+                idir = +1;
+                c1 = clow;
+                continue;
+            }
+            break;
+        }
+        const int s2 = replay_sign(wave, k, omega, c2, br, npts, nlit, nexec);
+        if (s1 != s2) break;
+        c1 = c2;
+        s1 = s2;
+        if (uni(c1 < cm || c1 >= betmx + dc)) return false;
+    }
+    double c3 = 0.5 * (c1 + c2);
+    int s3 = replay_sign(wave, k, omega, c3, br, npts, nlit, nexec);
+    for (int nctrl = 2; nctrl < 100; ++nctrl) {
+        if (s3 * s1 < 0) {
+            c2 = c3;
+        } else {
+            c1 = c3;
+            s1 = s3;
+        }
+        if (uni(fabs(c1 - c2) <= 1.0e-6 * c1)) break;
+        c3 = 0.5 * (c1 + c2);
+        s3 = replay_sign(wave, k, omega, c3, br, npts, nlit, nexec);
+    }
+    c1io = c3;
+    return uni(c3 <= betmx);
+}
+
+// ---- the curve ---------------------------------------------------------------
+// Fundamental-mode phase velocities c[0..P-1] (LDS) of the table in g_T, bit-identical to
+// phase_curve_wave(..., mode = 0, ...).  Returns MHD_ST_OK or MHD_ST_NOROOT.
+__device__ __attribute__((noinline)) int phase_curve_predicted(int wave, const double* t, int P,
+                                                               double tscale, double dc,
+                                                               double* c, EvalCount& cnt)
+{
+    const LayerTable& T = g_T;
+    PredictScratch& S = g_PS;
+    if (T.b[0] <= 0.0) return MHD_ST_NOROOT;
+    const int lane = threadIdx.x & 63;
+    dc = fabs(dc);
+    PROF_T0
+    int nP = predict_coarse(wave, t, 0, P, tscale, dc, 0.0, 0, cnt);
+    PROF_ADD(0)
+    S.trouble = (nP < 0) ? 9 : 0;
+    if (nP < 0) {
+        const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt);
+        PROF_ADD(5)
+        return r;
+    }
+    predict_refine(wave, t, 0, nP, tscale, cnt);
+    PROF_ADD(1)
+
+    const double cc = T.cc, betmx = T.betmx, cm = T.cc;
+    int s1st = 0, kstart = 0, repairs = 0;
+    for (;;) {
+        // replay periods kstart..nP-1 (c[kstart-1] and s1st are exact)
+        int npts = 0, kfail = -1;
+        unsigned long long nexec = 0;
+        double c1 = cc;
+        for (int k = kstart; k < nP; ++k) {
+            const bool ifirst = (k == 0);
+            double clow;
+            if (ifirst) {
+                clow = cc;
+                c1 = cc;
+            } else {
+                clow = cm;
+                c1 = uniform_value(c[k - 1]) - 1.5 * dc;
+            }
+            int nlit = 0;
+            const bool ok = replay_period(wave, k, t[k] / tscale, c1, clow, dc, cm, betmx, ifirst,
+                                          s1st, npts, nlit, nexec);
+            if (lane == 0) S.plit[k] = (unsigned short)nlit;
+            if (npts > NPTS) break;
+            if (!ok) {
+                kfail = k;
+                break;
+            }
+            c[k] = c1;
+        }
+        cnt.exec += nexec;
+        __syncthreads();
+        PROF_ADD(2)
+        if (npts > NPTS) {
+            const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
+            PROF_ADD(4)
+            return r;
+        }
+        // verify: really evaluate every abscissa the replay consumed
+        int first_bad = npts;
+        for (int base = 0; base < npts; base += 64) {
+            const int i = base + lane;
+            const bool act = i < npts;
+            bool bad = false;
+            if (act) {
+                const int k = S.pk[i];
+                const double omega = TWOPI / (t[k] / tscale);
+                bad = sgni(eval_secular(wave, omega, S.px[i]).m) != (int)S.ps[i];
+            }
+            const unsigned long long mask = __ballot(bad);
+            cnt.exec += (unsigned long long)__popcll(__ballot(act));
+            if (mask) {
+                first_bad = base + (int)__ffsll((long long)mask) - 1;
+                break;
+            }
+        }
+        PROF_ADD(3)
+        if (first_bad == npts) {
+            const int klast = (kfail >= 0) ? kfail : nP - 1;
+            for (int k = kstart; k <= klast; ++k) cnt.lit += S.plit[k];
+#ifdef MHD_PROFILE
+            if (lane == 0) atomicAdd(&g_prof[8], 1ull);
+#endif
+            if (kfail >= 0) return MHD_ST_NOROOT;
+            if (nP == P) return MHD_ST_OK;
+            // the predictor saw no root for period nP-1 but the search found one: go on
+            const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, nP, s1st);
+            PROF_ADD(4)
+            return r;
+        }
+        // periods before the first wrong sign are exact
+        const int kbad = S.pk[first_bad];
+        for (int k = kstart; k < kbad; ++k) cnt.lit += S.plit[k];
+#ifdef MHD_PROFILE
+        if (lane == 0) { atomicAdd(&g_prof[6], 1ull); if (blockIdx.x < 1024) g_blk[blockIdx.x * 8 + 6] += 1; }
+#endif
+        S.trouble = repairs + 1;
+        if (++repairs > 3) {
+            const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kbad, s1st);
+            PROF_ADD(4)
+#ifdef MHD_PROFILE
+            if (lane == 0) atomicAdd(&g_prof[7], (unsigned long long)(P - kbad));
+#endif
+            return r;
+        }
+        // redo that one period with the wave-sequential search, then go on predicting
+        const bool ifirst = (kbad == 0);
+        double cr = ifirst ? cc : c[kbad - 1] - 1.5 * dc;
+        const bool ok = solve_period_wave(T, wave, t[kbad] / tscale, cr, ifirst ? cc : cm, dc, cm,
+                                          betmx, ifirst, s1st, cnt);
+        PROF_ADD(4)
+        if (!ok) return MHD_ST_NOROOT;
+        c[kbad] = cr;
+        kstart = kbad + 1;
+        if (kstart >= P) return MHD_ST_OK;
+        // the sequential search may have moved to another branch than the predictor's:
+        // predict the remaining periods again, continuing from the root it found
+        nP = predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, cnt);
+        PROF_ADD(0)
+        if (nP < 0) {
+            const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
+            PROF_ADD(5)
+            return r;
+        }
+        predict_refine(wave, t, kstart, nP, tscale, cnt);
+        PROF_ADD(1)
+    }
+}
+
+// forward_model with the period-parallel curve where it applies (fundamental mode).
+__device__ inline int forward_predicted(const LayerTable& T, int wave, int mode, int itype,
+                                        const double* t, int P, double dc, double dt,
+                                        double* vel, double* scratch, EvalCount& cnt)
+{
+    if (mode != 0 || P > 255)
+        return forward_wave(T, wave, mode, itype, t, P, dc, dt, vel, scratch, cnt);
+    if (itype == MHD_PHASE) return phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt);
+    double* c1 = scratch;
+    double* c2 = scratch + P;
+    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt);
+    if (st != MHD_ST_OK) return st;
+    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt);
+    if (st != MHD_ST_OK) return st;
+    for (int k = 0; k < P; ++k) {
+        if (c1[k] > 0.0 && c2[k] > 0.0) {
+            const double t1 = t[k] / (1.0 + dt), t2 = t[k] / (1.0 - dt);
+            const double f1 = 1.0 / t1, f2 = 1.0 / t2;
+            vel[k] = (f1 - f2) / (f1 / c1[k] - f2 / c2[k]);
+        } else {
+            vel[k] = 0.0;
+        }
+    }
+    return MHD_ST_OK;
+}
+
+}  // namespace mhd

@@ -163,14 +163,17 @@ static bracket_t tighten(earth_t*E,double t,double x,double slope_dx, double flo
 
 // ---- Stage 1: coarse continuation with windows; returns number of rounds, fills coarse brackets (a,b,fa,fb)
 static long long g_rev=0, g_s1_rounds=0, g_s1_giveup=0, g_s2_rounds=0;
+static int g_policy=0; static long long g_rt[8]={0}; static long long g_res_hist[10]={0};
 static int stage1(earth_t*E,const double*periods,int P,double cc,double betmx,double dc,const double*hint,
                   double*A,double*Bb,long double*FA,long double*FB,int*found){
-    int rounds=0; int k0=0; double rprev=0; int sigma0=0;
+    int rounds=0; int k0=0; double rprev=0; int sigma0=0; double last_inc=0; int have_inc=0;
     double carry_s=cc; int carry=0; // continuing an unresolved period
     long double carry_f=0; int carry_sign=0;
     while(k0<P){
         // choose g
         int g=4;
+        if(g_policy==1 && k0>=2 && have_inc){ double inc=last_inc; if(inc<0)inc=0; if(8*inc+3<=8) g=8; else if(4*inc+3<=16) g=4; else if(2*inc+3<=32) g=2; else g=1; }
+        if(g_policy==2 && k0>=2 && have_inc){ double inc=last_inc; if(inc<0)inc=0; if(8*inc+4<=8) g=8; else if(4*inc+5<=16) g=4; else if(2*inc+6<=32) g=2; else g=1; }
         if(hint){ g=8; while(g>1){ int kl=k0+g-1; if(kl>=P)kl=P-1; double span=(hint[kl]-hint[k0>0?k0-1:0])/dc; if(span<0)span=0; if(span+6<=64/g)break; g/=2; } }
         if(k0==0||carry) g=1;
         if(k0+g>P) g=P-k0;
@@ -179,7 +182,7 @@ static int stage1(earth_t*E,const double*periods,int P,double cc,double betmx,do
         // evaluate
         static long double F[8][64];
         for(int jj=0;jj<g;jj++){ double om=TWOPI/periods[k0+jj]; for(int j=0;j<W;j++){ double x=s+j*dc; F[jj][j]=secular_true(E,om/x,om); g_pred_evals++; } }
-        rounds++;
+        rounds++; if(carry) g_rt[1]++; else if(k0==0) g_rt[0]++; else g_rt[2+ (g==8?3:g==4?2:g==2?1:0)]++;
         if(k0==0&&!carry) sigma0=isgn(F[0][0]);
         int resolved=0;
         for(int jj=0;jj<g;jj++){
@@ -201,9 +204,10 @@ static int stage1(earth_t*E,const double*periods,int P,double cc,double betmx,do
             if(!got){ // continue this period next round
                 carry=1; carry_s=s+W*dc; carry_sign=s1; carry_f=F[jj][W-1]; A[k]=s+(W-1)*dc; FA[k]=F[jj][W-1]; k0=k; goto next; }
             if(j-1>=0){ A[k]=s+(j-1)*dc; FA[k]=F[jj][j-1]; } // else A,FA from carry
-            Bb[k]=s+j*dc; FB[k]=F[jj][j]; found[k]=1; rprev=0.5*(A[k]+Bb[k]); resolved++; carry=0;
+            Bb[k]=s+j*dc; FB[k]=F[jj][j]; found[k]=1; { double nr=0.5*(A[k]+Bb[k]); if(k>0){ last_inc=(nr-rprev)/dc; have_inc=1;} rprev=nr; } resolved++; carry=0;
         }
         out:
+        g_res_hist[resolved<9?resolved:9]++;
         k0+=resolved; if(resolved==0 && !carry){ g_s1_giveup++; return -rounds; }
         next:;
         if(rounds>200){ g_s1_giveup++; return -rounds; }
@@ -254,6 +258,61 @@ static int stage1b(earth_t*E,const double*periods,int P,double cc,double betmx,d
         k0+=resolved;
         if(resolved<g/2 && gmax>1) gmax/=2; else if(resolved==g && gmax<8) gmax*=2;
         if(resolved==0){ gmax=1; }
+        next:;
+        if(rounds>300){ g_s1_giveup++; return -rounds; }
+    }
+    return rounds;
+}
+
+
+// ---- Stage 1c: per-period windows offset by the predicted increment
+static int stage1c(earth_t*E,const double*periods,int P,double cc,double betmx,double dc,
+                  double*A,double*Bb,long double*FA,long double*FB,int*found){
+    int rounds=0; int k0=0; double rprev=0; int sigma0=0; double inc=1.0; int have_inc=0;
+    int carry=0; double carry_base=0; int carry_sign=0;
+    while(k0<P){
+        int g;
+        if(k0==0||carry) g=1;
+        else { double ai=fabs(inc); if(!have_inc) g=4; else if(ai<=2.0) g=8; else if(ai<=5.0) g=4; else if(ai<=12) g=2; else g=1; }
+        if(k0+g>P) g=P-k0;
+        int W=64/g; if(g==5||g==6||g==7) W=8; if(g==3) W=16;
+        static long double F[8][64]; double base[8];
+        for(int jj=0;jj<g;jj++){
+            int k=k0+jj;
+            if(carry&&jj==0) base[jj]=carry_base;
+            else if(k==0) base[jj]=cc;
+            else { double pinc = have_inc? inc : 1.0; double pstart=rprev + jj*pinc*dc - 1.5*dc; int mlo = (jj==0)?0: (1+ (jj+1)/2); if(W>=16) mlo*=2; base[jj]=pstart - mlo*dc; if(base[jj]<cc-2*dc) base[jj]=cc-2*dc; }
+            double om=TWOPI/periods[k]; for(int j=0;j<W;j++){ double x=base[jj]+j*dc; F[jj][j]=secular_true(E,om/x,om); g_pred_evals++; }
+        }
+        rounds++; if(carry) g_rt[1]++; else if(k0==0) g_rt[0]++; else g_rt[2+ (g>=8?3:g>=4?2:g>=2?1:0)]++;
+        if(k0==0&&!carry) sigma0=isgn(F[0][0]);
+        int resolved=0;
+        for(int jj=0;jj<g;jj++){
+            int k=k0+jj; int start; int s1; double s=base[jj];
+            if(carry&&jj==0){ start=-1; s1=carry_sign; }
+            else if(k==0){ start=0; s1=isgn(F[0][0]); }
+            else { double st=rprev-1.5*dc; double off=(st-s)/dc; if(off<-1e-9) break; start=(int)floor(off+1e-9); if(start>=W-1) break; s1=isgn(F[jj][start]);
+                   if(s1*sigma0<0){
+                       // reversed: look downward inside the window
+                       int j2; int gotd=0; for(j2=start-1;j2>=0;j2--){ if(isgn(F[jj][j2])!=s1){gotd=1;break;} }
+                       if(gotd){ A[k]=s+j2*dc; FA[k]=F[jj][j2]; Bb[k]=s+(j2+1)*dc; FB[k]=F[jj][j2+1]; found[k]=1; double nr=0.5*(A[k]+Bb[k]); inc=(nr-rprev)/dc; have_inc=1; rprev=nr; resolved++; g_rev++; continue; }
+                       if(resolved>0) break;
+                       double om=TWOPI/periods[k]; long double fprev=secular_true(E,om/st,om); g_pred_evals++; int sp=isgn(fprev); double xp=st;
+                       for(j2=1;j2<64;j2++){ double x=st-j2*dc; if(x<=cc){break;} long double f=secular_true(E,om/x,om); g_pred_evals++; if(isgn(f)!=sp){ A[k]=x;FA[k]=f;Bb[k]=xp;FB[k]=fprev;gotd=1;break;} xp=x;fprev=f; }
+                       rounds++; g_rt[6]++;
+                       if(!gotd){ g_s1_giveup++; return -rounds; }
+                       found[k]=1; { double nr=0.5*(A[k]+Bb[k]); inc=(nr-rprev)/dc; have_inc=1; rprev=nr; } resolved++; g_rev++;
+                       break; } }
+            int j; int got=0;
+            for(j=start+1;j<W;j++){ if(isgn(F[jj][j])!=s1){ got=1;break;} if(s+j*dc>=betmx+dc){ found[k]=0; return rounds; } }
+            if(!got){ if(jj>0 && !(carry&&jj==0)) { /* let the next round restart this period with its own window */ break; }
+                      carry=1; carry_base=s+W*dc; carry_sign=s1; A[k]=s+(W-1)*dc; FA[k]=F[jj][W-1]; k0=k; goto next; }
+            if(j-1>=0){ A[k]=s+(j-1)*dc; FA[k]=F[jj][j-1]; }
+            Bb[k]=s+j*dc; FB[k]=F[jj][j]; found[k]=1; { double nr=0.5*(A[k]+Bb[k]); if(k>0){ inc=(nr-rprev)/dc; have_inc=1;} rprev=nr; } resolved++; carry=0;
+        }
+        g_res_hist[resolved<9?resolved:9]++;
+        k0+=resolved;
+        if(resolved==0){ if(g==1 && !carry){ g_s1_giveup++; return -rounds; } inc = (fabs(inc)+1)*4; /* widen */ }
         next:;
         if(rounds>300){ g_s1_giveup++; return -rounds; }
     }
@@ -324,7 +383,7 @@ static int replay_period(earth_t*E, bracket_t*B, int k, double t1,double*c1io,do
 int main(int argc,char**argv){
     int nl=6,P=40; int NP=2*nl+1;
     int nchains=200, nsteps=200;
-    if(argc>1)TOLREL=atof(argv[1]); if(argc>2)g_use_homotopy=atoi(argv[2]); if(argc>3)HV=atof(argv[3]); if(argc>4)HD=atof(argv[4]);
+    if(argc>1)TOLREL=atof(argv[1]); if(argc>2)g_use_homotopy=atoi(argv[2]); if(argc>3)HV=atof(argv[3]); if(argc>4)HD=atof(argv[4]); if(argc>5)g_policy=atoi(argv[5]);
     double periods[128]; for(int k=0;k<P;k++){ double f=pow(10.0,0.3+(1.3-0.3)*(P-1-k)/(P-1)); periods[k]=1.0/f; }
     double lo[32],hi[32]; for(int i=0;i<nl;i++){lo[i]=0.001;hi[i]=0.15;} for(int i=nl;i<NP;i++){lo[i]=0.1;hi[i]=2.0;}
     srand48(1);
@@ -357,7 +416,7 @@ int main(int argc,char**argv){
             bracket_t Bk[128]; int maxit=0;
             if(g_use_homotopy>=2){
                 double A[128],Bb[128]; long double FA[128],FB[128]; int fnd[128]; for(int k=0;k<P;k++)fnd[k]=0;
-                int r= g_use_homotopy>=4 ? stage1b(&E,periods,P,cc,betmx,dc,g_use_homotopy==5?cur:NULL,A,Bb,FA,FB,fnd) : stage1(&E,periods,P,cc,betmx,dc,g_use_homotopy==3?cur:NULL,A,Bb,FA,FB,fnd);
+                int r= g_use_homotopy==6 ? stage1c(&E,periods,P,cc,betmx,dc,A,Bb,FA,FB,fnd) : g_use_homotopy>=4 ? stage1b(&E,periods,P,cc,betmx,dc,g_use_homotopy==5?cur:NULL,A,Bb,FA,FB,fnd) : stage1(&E,periods,P,cc,betmx,dc,g_use_homotopy==3?cur:NULL,A,Bb,FA,FB,fnd);
                 if(r<0){ /* give up -> v1 */ g_s1_rounds+=-r; g_curves++; g_points+=0; continue; }
                 g_s1_rounds+=r; int mx2=0;
                 for(int k=0;k<P;k++){ if(fnd[k]){ int it; Bk[k]=refine_illinois(&E,periods[k],A[k],Bb[k],FA[k],FB[k],&it); if(it>mx2)mx2=it; hist_it[it<63?it:63]++; g_lanes++; g_itersum+=it; } else { Bk[k].lo=1e300;Bk[k].hi=1e301;Bk[k].slo=Bk[k].shi=sigma0; } }
@@ -390,6 +449,6 @@ int main(int argc,char**argv){
     }
     printf("tol %g curves %lld lit/curve %.1f pred_evals/curve %.1f avg_iters/lane %.2f avg_max_iters %.2f points/curve %.1f ties/curve %.4f mismatch_curves %lld (%.3f%%) noroot %lld\n",TOLREL,
         g_curves,(double)lit_total/g_curves,(double)g_pred_evals/g_curves,(double)g_itersum/g_lanes,(double)g_maxiter/g_curves,(double)g_points/g_curves,(double)g_ties/g_curves,g_mismatch_curves,100.0*g_mismatch_curves/g_curves,g_fail_curves);
-    printf("reversed periods %lld ",g_rev); printf("avg nsub %.2f s1 rounds/curve %.2f s2 rounds/curve %.2f giveup %lld\n",(double)g_nsub_sum/g_curves,(double)g_s1_rounds/g_curves,(double)g_s2_rounds/g_curves,g_s1_giveup); printf("iters hist:"); for(int i=0;i<40;i++)printf(" %lld",hist_it[i]); printf("\n");
+    printf("round types: k0 %lld carry %lld g1 %lld g2 %lld g4 %lld g8 %lld | resolved hist:",g_rt[0],g_rt[1],g_rt[2],g_rt[3],g_rt[4],g_rt[5]); printf(" rev %lld ",g_rt[6]); for(int i=0;i<10;i++)printf(" %lld",g_res_hist[i]); printf("\n"); printf("reversed periods %lld ",g_rev); printf("avg nsub %.2f s1 rounds/curve %.2f s2 rounds/curve %.2f giveup %lld\n",(double)g_nsub_sum/g_curves,(double)g_s1_rounds/g_curves,(double)g_s2_rounds/g_curves,g_s1_giveup); printf("iters hist:"); for(int i=0;i<40;i++)printf(" %lld",hist_it[i]); printf("\n");
     return 0;
 }
