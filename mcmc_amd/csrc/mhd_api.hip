@@ -273,6 +273,9 @@ __global__ __launch_bounds__(64) void mh_steps_kernel(
                 st = forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred, scratch,
                                   cnt);
                 if (penalty > 0) --penalty;
+#ifdef MHD_PROFILE
+                if (lane == 0 && ib < 1024) g_blk[ib * 8 + 7] += 1;
+#endif
             }
             __syncthreads();
         }

@@ -44,7 +44,21 @@ struct LayerTable {
 
 // The layer table of the chain this workgroup works on.  File scope so that the one
 // out-of-line secular-function body reads it with LDS instructions, not through a pointer.
-__shared__ LayerTable g_T;
+// One instance per wave of the workgroup (the Metropolis-Hastings kernel runs two waves, each
+// with its own candidate model); g_T is the instance of the calling wave.
+constexpr int NWAVE = 2;
+__shared__ LayerTable g_Tw[NWAVE];
+#define g_T (g_Tw[threadIdx.x >> 6])
+
+// Orders the LDS accesses of ONE wave (its lanes run in lock step, LDS operations of a wave
+// complete in order): a compiler fence, no hardware barrier.  Waves of a workgroup that work
+// on different candidates must not meet in __syncthreads().
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ int sgni(double x) { return (x > 0.0) - (x < 0.0); }
 
@@ -299,7 +313,7 @@ __device__ inline void build_layer_table(LayerTable& T, const double* m, int n_l
         T.inv_rho[lane] = 1.0 / rho;
         T.twob2[lane] = 2.0 * vs * vs;
     }
-    __syncthreads();
+    wave_sync();
     // extremal velocities and start value (uniform, every lane computes the same)
     double betmx = -1.0e20, betmn = 1.0e20;
     int jmn = 0, jsol = 1;
@@ -323,7 +337,7 @@ __device__ inline void build_layer_table(LayerTable& T, const double* m, int n_l
         T.betmx = betmx;
         T.L = L;
     }
-    __syncthreads();
+    wave_sync();
 }
 
 struct EvalCount {
@@ -635,9 +649,9 @@ __device__ inline double loglik_wave(const mhd_problem_t& p, const double* pred,
             term[k] = log(lam / (kap + (1.0 / kap))) - (((r * lam) * s) * kps);
         }
     }
-    __syncthreads();
+    wave_sync();
     const double sum = npsum_small(term, P);
-    __syncthreads();
+    wave_sync();
     return (p.noise_dist == MHD_NORMAL) ? -sum : sum;
 }
 
