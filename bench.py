@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--search", type=int, default=2,
                     help="2 = period-parallel root search (default), 1 = wave-sequential")
+    ap.add_argument("--candidates", type=int, default=2,
+                    help="2 = two candidates per chain in flight (default), 1 = one")
     args = ap.parse_args()
 
     import torch
@@ -113,6 +115,7 @@ def main():
     from mcmc_amd.engine import DeviceChains, DeviceProblem
     from mcmc_amd import _lib as L
     L.check(L.lib().mhd_set_search(args.search))
+    L.check(L.lib().mhd_set_candidates(args.candidates))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -199,7 +202,8 @@ def main():
                             "inversion, 1024 independent chains x 40 periods per GPU",
                 "chains_per_gpu": B, "n_periods": N_PERIODS, "n_layers": N_LAYERS,
                 "proposal": "cauchy", "likelihood": "normal", "rotation": "off",
-                "steps_per_launch": args.chunk, "search": args.search, "acceptance_rate": round(acc_rate, 4),
+                "steps_per_launch": args.chunk, "search": args.search,
+                "candidates_in_flight": args.candidates, "acceptance_rate": round(acc_rate, 4),
             },
             "roofline": {
                 "bound": "valu_fp64",
@@ -208,7 +212,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": None,
-                "kernel": "mh_steps_kernel",
+                "kernel": "mh_steps_pair_kernel" if args.candidates == 2 else "mh_steps_kernel",
                 "launch_ms": launch_s * 1e3,
                 "algorithmic_evals_per_launch": lit / n_launch,
                 "executed_evals_per_launch": ex / n_launch,

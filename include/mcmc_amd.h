@@ -114,6 +114,16 @@ const char *mhd_last_error(void);
 int mhd_set_search(int32_t algorithm);
 
 /*
+ * Candidates mhd_mh_steps evaluates at the same time per chain, process-wide:
+ * 2 (default) = the next two proposals that pass the bounds run the forward
+ * model concurrently (two waves per chain) and the steps are settled in order,
+ * the second result being used only when the first candidate was rejected;
+ * 1 = one candidate at a time.  The chain of states is the same either way;
+ * no counterpart in the reference.  sample_prior runs always use 1.
+ */
+int mhd_set_candidates(int32_t n);
+
+/*
  * Secular (period-equation) function values, for diagnostics and parity gates:
  * delta[i] = Delta(c[i]) of chain chain[i] at period index period[i].
  * Replaces nothing the reference calls directly; it is disba's dltar4 / dltar1

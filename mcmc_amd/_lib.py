@@ -24,6 +24,7 @@ EXPORTS = (
     "mhd_abi_version",
     "mhd_last_error",
     "mhd_set_search",
+    "mhd_set_candidates",
     "mhd_secular_batch",
     "mhd_forward_batch",
     "mhd_loglik_batch",
@@ -75,6 +76,7 @@ def lib():
     L.mhd_last_error.restype = ctypes.c_char_p
     L.mhd_last_error.argtypes = []
     L.mhd_set_search.argtypes = [c_int32]
+    L.mhd_set_candidates.argtypes = [c_int32]
     L.mhd_secular_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                     c_void_p, c_void_p]
     L.mhd_forward_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]

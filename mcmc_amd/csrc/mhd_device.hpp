@@ -46,7 +46,15 @@ struct LayerTable {
 // out-of-line secular-function body reads it with LDS instructions, not through a pointer.
 // One instance per wave of the workgroup (the Metropolis-Hastings kernel runs two waves, each
 // with its own candidate model); g_T is the instance of the calling wave.
-constexpr int NWAVE = 2;
+#ifndef MHD_NWAVE
+#define MHD_NWAVE 2
+#endif
+constexpr int NWAVE = MHD_NWAVE;
+
+// Out-of-line routines share one register budget: VGPRs + AGPRs <= 256, so that two waves fit
+// on a SIMD (512 registers per lane) and hide each other's FP64 latency.
+#define MHD_REGS __attribute__((amdgpu_waves_per_eu(2, 2)))
+#define MHD_NOINLINE __attribute__((noinline))
 __shared__ LayerTable g_Tw[NWAVE];
 #define g_T (g_Tw[threadIdx.x >> 6])
 
@@ -238,7 +246,7 @@ struct SecVal {
 
 // The ONE out-of-line body of the period equation (keeps the kernels within the
 // instruction cache: every search stage calls this instead of inlining a copy).
-__device__ __attribute__((noinline)) SecVal eval_secular(int wave, double omega, double c)
+__device__ MHD_NOINLINE SecVal eval_secular(int wave, double omega, double c)
 {
     SecVal v;
     omega = fmax(omega, 1.0e-4);
@@ -375,7 +383,7 @@ __device__ __forceinline__ double scan_next(double& c1, int& idir, double clow, 
 // sign change lies in one of those cells -- the usual case -- three halvings are
 // already done.  Further rounds evaluate 64 scan abscissae, or the 63 nodes of a
 // 6-level tree.
-__device__ __attribute__((noinline)) bool solve_period_wave(const LayerTable& T, int wave, double t1, double& c1io,
+__device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, double t1, double& c1io,
                                          double clow, double dc, double cm, double betmx,
                                          bool ifirst, int& s1st, EvalCount& cnt)
 {
@@ -540,7 +548,7 @@ __device__ __attribute__((noinline)) bool solve_period_wave(const LayerTable& T,
 // c[] in LDS.  Wave-uniform.  Returns MHD_ST_OK or MHD_ST_NOROOT.
 // kstart > 0 resumes the fundamental mode at period kstart: c[0..kstart-1] and
 // the sign of the first secular value of period 0 (s1st) are then inputs.
-__device__ __attribute__((noinline)) int phase_curve_wave(const LayerTable& T, int wave, const double* t, int P,
+__device__ MHD_NOINLINE int phase_curve_wave(const LayerTable& T, int wave, const double* t, int P,
                                        double tscale, int mode, double dc, double* c,
                                        EvalCount& cnt, int kstart = 0, int s1st = 0)
 {

@@ -25,12 +25,14 @@
 
 namespace mhd {
 
-constexpr int NPTS = 1536;
+constexpr int NPTS = 512;      // abscissae verified per pass (a long curve takes several passes)
+constexpr int MAX_REPAIRS = 3;  // then the wave-sequential search finishes the curve
+constexpr int NPTS_ROOM = 96;  // a new period is started only with this much room left
 
 struct PredictScratch {
     double lo[MAXP], hi[MAXP];    // root bracket per period (stage 1: one dc cell)
-    double fam[MAXP], fbm[MAXP];  // tracked values at the bracket ends: mantissa ...
-    int fae[MAXP], fbe[MAXP];     // ... and binary exponent
+    float fam[MAXP], fbm[MAXP];   // tracked values at the bracket ends: mantissa ...
+    short fae[MAXP], fbe[MAXP];   // ... and binary exponent (start values of stage 2 only)
     signed char slo[MAXP], shi[MAXP];
     double fm[64];  // lane values of the current stage-1 round
     int fe[64];
@@ -41,7 +43,8 @@ struct PredictScratch {
     int trouble;  // repairs the last predicted curve needed (9: the predictor gave up)
 };
 
-__shared__ PredictScratch g_PS;
+__shared__ PredictScratch g_PSw[NWAVE];
+#define g_PS (g_PSw[threadIdx.x >> 6])
 
 #pragma clang fp contract(off)
 
@@ -67,7 +70,7 @@ __device__ __forceinline__ int mask_sign(unsigned long long neg, unsigned long l
 // function of period 0 at the floor).
 // n < P: period n-1 has no sign change below the ceiling (its bracket is "constant sign"),
 // the sequential search fails there.  -1: give up (the caller uses the sequential search).
-__device__ __attribute__((noinline)) int predict_coarse(int wave, const double* t, int kbeg,
+__device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg,
                                                         int P, double tscale, double dc,
                                                         double rprev_in, int sigma0_in,
                                                         EvalCount& cnt)
@@ -111,10 +114,10 @@ __device__ __attribute__((noinline)) int predict_coarse(int wave, const double* 
         }
         const unsigned long long neg = __ballot(active && v.m < 0.0);
         const unsigned long long pos = __ballot(active && v.m > 0.0);
-        __syncthreads();
+        wave_sync();
         S.fm[lane] = v.m;
         S.fe[lane] = v.e;
-        __syncthreads();
+        wave_sync();
         cnt.exec += (unsigned long long)(gact * W);
         if (k0 == 0 && !carry) sigma0 = mask_sign(neg, pos, 0);
 
@@ -144,11 +147,11 @@ __device__ __attribute__((noinline)) int predict_coarse(int wave, const double* 
                         if (mask_sign(neg, pos, bit0 + j2) != s1) break;
                     if (j2 >= 0) {
                         S.lo[k] = s + j2 * dc;
-                        S.fam[k] = S.fm[bit0 + j2];
-                        S.fae[k] = S.fe[bit0 + j2];
+                        S.fam[k] = (float)S.fm[bit0 + j2];
+                        S.fae[k] = (short)S.fe[bit0 + j2];
                         S.hi[k] = s + (j2 + 1) * dc;
-                        S.fbm[k] = S.fm[bit0 + j2 + 1];
-                        S.fbe[k] = S.fe[bit0 + j2 + 1];
+                        S.fbm[k] = (float)S.fm[bit0 + j2 + 1];
+                        S.fbe[k] = (short)S.fe[bit0 + j2 + 1];
                         const double nr = s + (j2 + 0.5) * dc;
                         inc = (nr - rprev) / dc;
                         have_inc = true;
@@ -166,10 +169,10 @@ __device__ __attribute__((noinline)) int predict_coarse(int wave, const double* 
                     const unsigned long long ng = __ballot(act && vd.m < 0.0);
                     const unsigned long long ps = __ballot(act && vd.m > 0.0);
                     const unsigned long long am = __ballot(act);
-                    __syncthreads();
+                    wave_sync();
                     S.fm[lane] = vd.m;
                     S.fe[lane] = vd.e;
-                    __syncthreads();
+                    wave_sync();
                     cnt.exec += (unsigned long long)__popcll(am);
                     const int sd = mask_sign(ng, ps, 0);
                     int j3 = 1;
@@ -179,11 +182,11 @@ __device__ __attribute__((noinline)) int predict_coarse(int wave, const double* 
                     }
                     if (j3 >= 64) return -1;
                     S.lo[k] = st - j3 * dc;
-                    S.fam[k] = S.fm[j3];
-                    S.fae[k] = S.fe[j3];
+                    S.fam[k] = (float)S.fm[j3];
+                    S.fae[k] = (short)S.fe[j3];
                     S.hi[k] = st - (j3 - 1) * dc;
-                    S.fbm[k] = S.fm[j3 - 1];
-                    S.fbe[k] = S.fe[j3 - 1];
+                    S.fbm[k] = (float)S.fm[j3 - 1];
+                    S.fbe[k] = (short)S.fe[j3 - 1];
                     const double nr = st - (j3 - 0.5) * dc;
                     inc = (nr - rprev) / dc;
                     have_inc = true;
@@ -203,11 +206,11 @@ __device__ __attribute__((noinline)) int predict_coarse(int wave, const double* 
                     // no sign change below the ceiling: the sequential search fails here
                     S.lo[k] = 1.0e300;
                     S.hi[k] = 1.0e301;
-                    S.fam[k] = (double)s1;
-                    S.fbm[k] = (double)s1;
+                    S.fam[k] = (float)s1;
+                    S.fbm[k] = (float)s1;
                     S.fae[k] = 0;
                     S.fbe[k] = 0;
-                    __syncthreads();
+                    wave_sync();
                     return k + 1;
                 }
             }
@@ -218,18 +221,18 @@ __device__ __attribute__((noinline)) int predict_coarse(int wave, const double* 
                 carry_base = s + W * dc;
                 carry_sign = s1;
                 S.lo[k] = s + (W - 1) * dc;
-                S.fam[k] = S.fm[bit0 + W - 1];
-                S.fae[k] = S.fe[bit0 + W - 1];
+                S.fam[k] = (float)S.fm[bit0 + W - 1];
+                S.fae[k] = (short)S.fe[bit0 + W - 1];
                 break;
             }
             if (jn - 1 >= 0) {
                 S.lo[k] = s + (jn - 1) * dc;
-                S.fam[k] = S.fm[bit0 + jn - 1];
-                S.fae[k] = S.fe[bit0 + jn - 1];
+                S.fam[k] = (float)S.fm[bit0 + jn - 1];
+                S.fae[k] = (short)S.fe[bit0 + jn - 1];
             }
             S.hi[k] = s + jn * dc;
-            S.fbm[k] = S.fm[bit0 + jn];
-            S.fbe[k] = S.fe[bit0 + jn];
+            S.fbm[k] = (float)S.fm[bit0 + jn];
+            S.fbe[k] = (short)S.fe[bit0 + jn];
             const double nr = s + (jn - 0.5) * dc;
             if (k > 0) {
                 inc = (nr - rprev) / dc;
@@ -245,12 +248,12 @@ __device__ __attribute__((noinline)) int predict_coarse(int wave, const double* 
             inc = (fabs(inc) + 1.0) * 4.0;  // widen the windows
         }
     }
-    __syncthreads();
+    wave_sync();
     return P;
 }
 
 // ---- stage 2 ----------------------------------------------------------------
-__device__ __attribute__((noinline)) void predict_refine(int wave, const double* t, int kbeg,
+__device__ MHD_NOINLINE void predict_refine(int wave, const double* t, int kbeg,
                                                          int P, double tscale, EvalCount& cnt)
 {
     PredictScratch& S = g_PS;
@@ -312,7 +315,7 @@ __device__ __attribute__((noinline)) void predict_refine(int wave, const double*
             S.shi[k] = (signed char)sb;
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // ---- stage 3 ----------------------------------------------------------------
@@ -400,7 +403,7 @@ __device__ __forceinline__ bool replay_period(int wave, int k, double t1, double
 // ---- the curve ---------------------------------------------------------------
 // Fundamental-mode phase velocities c[0..P-1] (LDS) of the table in g_T, bit-identical to
 // phase_curve_wave(..., mode = 0, ...).  Returns MHD_ST_OK or MHD_ST_NOROOT.
-__device__ __attribute__((noinline)) int phase_curve_predicted(int wave, const double* t, int P,
+__device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int P,
                                                                double tscale, double dc,
                                                                double* c, EvalCount& cnt)
 {
@@ -424,11 +427,14 @@ __device__ __attribute__((noinline)) int phase_curve_predicted(int wave, const d
     const double cc = T.cc, betmx = T.betmx, cm = T.cc;
     int s1st = 0, kstart = 0, repairs = 0;
     for (;;) {
-        // replay periods kstart..nP-1 (c[kstart-1] and s1st are exact)
-        int npts = 0, kfail = -1;
+        // replay periods kstart..kend-1 (c[kstart-1] and s1st are exact); a pass ends when the
+        // abscissa list is nearly full
+        int npts = 0, kfail = -1, kend = kstart;
         unsigned long long nexec = 0;
         double c1 = cc;
+        bool overflow = false;
         for (int k = kstart; k < nP; ++k) {
+            if (k > kstart && npts > NPTS - NPTS_ROOM) break;
             const bool ifirst = (k == 0);
             double clow;
             if (ifirst) {
@@ -439,10 +445,20 @@ __device__ __attribute__((noinline)) int phase_curve_predicted(int wave, const d
                 c1 = uniform_value(c[k - 1]) - 1.5 * dc;
             }
             int nlit = 0;
+            const int npts0 = npts;
+            const int s1st0 = s1st;
             const bool ok = replay_period(wave, k, t[k] / tscale, c1, clow, dc, cm, betmx, ifirst,
                                           s1st, npts, nlit, nexec);
+            if (npts > NPTS) {
+                // this period did not fit: verify the earlier ones first, or (alone) give it to
+                // the wave-sequential search
+                npts = npts0;
+                s1st = s1st0;
+                overflow = (k == kstart);
+                break;
+            }
             if (lane == 0) S.plit[k] = (unsigned short)nlit;
-            if (npts > NPTS) break;
+            kend = k + 1;
             if (!ok) {
                 kfail = k;
                 break;
@@ -450,81 +466,122 @@ __device__ __attribute__((noinline)) int phase_curve_predicted(int wave, const d
             c[k] = c1;
         }
         cnt.exec += nexec;
-        __syncthreads();
+        wave_sync();
         PROF_ADD(2)
-        if (npts > NPTS) {
+        if (overflow) {
             const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
             PROF_ADD(4)
             return r;
         }
         // verify: really evaluate every abscissa the replay consumed
-        int first_bad = npts;
-        for (int base = 0; base < npts; base += 64) {
-            const int i = base + lane;
-            const bool act = i < npts;
-            bool bad = false;
-            if (act) {
-                const int k = S.pk[i];
-                const double omega = TWOPI / (t[k] / tscale);
-                bad = sgni(eval_secular(wave, omega, S.px[i]).m) != (int)S.ps[i];
+        int vbeg = 0, klit = kstart;  // first unverified abscissa; first period not yet counted
+        bool again = false;           // replay again from kstart
+        for (;;) {
+            int first_bad = npts;
+            for (int base = vbeg; base < npts; base += 64) {
+                const int i = base + lane;
+                const bool act = i < npts;
+                bool bad = false;
+                if (act) {
+                    const int k = S.pk[i];
+                    const double omega = TWOPI / (t[k] / tscale);
+                    bad = sgni(eval_secular(wave, omega, S.px[i]).m) != (int)S.ps[i];
+                }
+                const unsigned long long mask = __ballot(bad);
+                cnt.exec += (unsigned long long)__popcll(__ballot(act));
+                if (mask) {
+                    first_bad = base + (int)__ffsll((long long)mask) - 1;
+                    break;
+                }
             }
-            const unsigned long long mask = __ballot(bad);
-            cnt.exec += (unsigned long long)__popcll(__ballot(act));
-            if (mask) {
-                first_bad = base + (int)__ffsll((long long)mask) - 1;
+            PROF_ADD(3)
+            if (first_bad == npts) break;
+            // periods before the first wrong sign are exact
+            const int kbad = S.pk[first_bad];
+            for (int k = klit; k < kbad; ++k) cnt.lit += S.plit[k];
+            klit = kbad + 1;
+#ifdef MHD_PROFILE
+            if (lane == 0) { atomicAdd(&g_prof[6], 1ull); if (blockIdx.x < 1024) g_blk[blockIdx.x * 8 + 6] += 1; }
+#endif
+            S.trouble = repairs + 1;
+            if (++repairs > MAX_REPAIRS) {
+                const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kbad, s1st);
+                PROF_ADD(4)
+#ifdef MHD_PROFILE
+                if (lane == 0) atomicAdd(&g_prof[7], (unsigned long long)(P - kbad));
+#endif
+                return r;
+            }
+            // redo that one period with the wave-sequential search
+            const bool ifirst = (kbad == 0);
+            const double cold = (kfail == kbad) ? -1.0 : uniform_value(c[kbad]);
+            double cr = ifirst ? cc : uniform_value(c[kbad - 1]) - 1.5 * dc;
+            const bool ok = solve_period_wave(T, wave, t[kbad] / tscale, cr, ifirst ? cc : cm, dc,
+                                              cm, betmx, ifirst, s1st, cnt);
+            PROF_ADD(4)
+            if (!ok) return MHD_ST_NOROOT;
+            c[kbad] = cr;
+            wave_sync();
+            if (kbad + 1 >= P) return MHD_ST_OK;
+            if (uni(cr == cold)) {
+                // same answer: the replay of the later periods stands; verify on from the
+                // first abscissa of the next period
+                int nb = npts;
+                for (int base = first_bad + 1; base < npts; base += 64) {
+                    const int i = base + lane;
+                    const unsigned long long mk = __ballot(i < npts && (int)S.pk[i] > kbad);
+                    if (mk) {
+                        nb = base + (int)__ffsll((long long)mk) - 1;
+                        break;
+                    }
+                }
+                vbeg = nb;
+#ifdef MHD_PROFILE
+                if (lane == 0) atomicAdd(&g_prof[11], 1ull);
+#endif
+                continue;
+            }
+            kstart = kbad + 1;
+            again = true;
+            const double plo = uniform_value(S.lo[kbad]), phi = uniform_value(S.hi[kbad]);
+            if (kbad < nP - 1 && uni(cr >= plo - 2.0e-6 * cr && cr <= phi + 2.0e-6 * cr)) {
+                // same root on another lattice: the predictions for the later periods stand
+#ifdef MHD_PROFILE
+                if (lane == 0) atomicAdd(&g_prof[12], 1ull);
+#endif
                 break;
             }
-        }
-        PROF_ADD(3)
-        if (first_bad == npts) {
-            const int klast = (kfail >= 0) ? kfail : nP - 1;
-            for (int k = kstart; k <= klast; ++k) cnt.lit += S.plit[k];
 #ifdef MHD_PROFILE
-            if (lane == 0) atomicAdd(&g_prof[8], 1ull);
+            if (lane == 0) atomicAdd(&g_prof[13], 1ull);
 #endif
-            if (kfail >= 0) return MHD_ST_NOROOT;
-            if (nP == P) return MHD_ST_OK;
-            // the predictor saw no root for period nP-1 but the search found one: go on
-            const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, nP, s1st);
-            PROF_ADD(4)
-            return r;
+            // the sequential search moved to another branch than the predictor's: predict the
+            // remaining periods again, continuing from the root it found
+            nP = predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, cnt);
+            PROF_ADD(0)
+            if (nP < 0) {
+                const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
+                PROF_ADD(5)
+                return r;
+            }
+            predict_refine(wave, t, kstart, nP, tscale, cnt);
+            PROF_ADD(1)
+            break;
         }
-        // periods before the first wrong sign are exact
-        const int kbad = S.pk[first_bad];
-        for (int k = kstart; k < kbad; ++k) cnt.lit += S.plit[k];
+        if (again) continue;
+        for (int k = klit; k < kend; ++k) cnt.lit += S.plit[k];
 #ifdef MHD_PROFILE
-        if (lane == 0) { atomicAdd(&g_prof[6], 1ull); if (blockIdx.x < 1024) g_blk[blockIdx.x * 8 + 6] += 1; }
+        if (lane == 0 && (kend >= nP || kfail >= 0)) atomicAdd(&g_prof[8], 1ull);
 #endif
-        S.trouble = repairs + 1;
-        if (++repairs > 3) {
-            const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kbad, s1st);
-            PROF_ADD(4)
-#ifdef MHD_PROFILE
-            if (lane == 0) atomicAdd(&g_prof[7], (unsigned long long)(P - kbad));
-#endif
-            return r;
+        if (kfail >= 0) return MHD_ST_NOROOT;
+        if (kend < nP) {  // next pass
+            kstart = kend;
+            continue;
         }
-        // redo that one period with the wave-sequential search, then go on predicting
-        const bool ifirst = (kbad == 0);
-        double cr = ifirst ? cc : c[kbad - 1] - 1.5 * dc;
-        const bool ok = solve_period_wave(T, wave, t[kbad] / tscale, cr, ifirst ? cc : cm, dc, cm,
-                                          betmx, ifirst, s1st, cnt);
+        if (nP == P) return MHD_ST_OK;
+        // the predictor saw no root for period nP-1 but the search found one: go on
+        const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, nP, s1st);
         PROF_ADD(4)
-        if (!ok) return MHD_ST_NOROOT;
-        c[kbad] = cr;
-        kstart = kbad + 1;
-        if (kstart >= P) return MHD_ST_OK;
-        // the sequential search may have moved to another branch than the predictor's:
-        // predict the remaining periods again, continuing from the root it found
-        nP = predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, cnt);
-        PROF_ADD(0)
-        if (nP < 0) {
-            const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
-            PROF_ADD(5)
-            return r;
-        }
-        predict_refine(wave, t, kstart, nP, tscale, cnt);
-        PROF_ADD(1)
+        return r;
     }
 }
 

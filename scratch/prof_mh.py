@@ -15,7 +15,7 @@ lib.mhd_debug_profile(out,0)
 o=list(out); n=1024*500*0.87
 print("value %.0f ms/step %.3f exec/lit %.2f"%(d['value'], d['ms_per_step'], d['roofline']['executed_evals_per_launch']/d['roofline']['algorithmic_evals_per_launch']))
 print("kernel cycles per wave-step %.0f, wallclock ticks(100MHz) per wave-step %.1f => clock %.2f GHz, => us per step %.1f"%(o[9]/(1024*500), o[10]/(1024*500), o[9]/max(o[10],1)/10.0, o[10]/(1024*500)/100.0))
-print("cycles per forward: coarse %.0f refine %.0f replay %.0f verify %.0f repair %.0f giveup %.0f | mismatch events %d v1-tail periods %d clean %d"%tuple([o[i]/n for i in range(6)]+[o[6],o[7],o[8]]))
+print("cycles per forward: coarse %.0f refine %.0f replay %.0f verify %.0f repair %.0f giveup %.0f | mismatch events %d v1-tail periods %d clean %d | repairs: same-c %d same-root %d re-predict %d"%tuple([o[i]/n for i in range(6)]+[o[6],o[7],o[8],o[11],o[12],o[13]]))
 
 import numpy as np
 tt=(ctypes.c_ulonglong*4096)()

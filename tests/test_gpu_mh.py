@@ -9,6 +9,15 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[2, 1], ids=["pair", "single"])
+def candidates(request):
+    """Every test runs with two candidates per chain in flight (the default) and with one."""
+    from mcmc_amd import _lib as L
+    L.check(L.lib().mhd_set_candidates(request.param))
+    yield request.param
+    L.check(L.lib().mhd_set_candidates(2))
+
+
 def _noise(g):
     return {k: (np.array(v) if isinstance(v, list) else v) for k, v in g["noise_params"].items()}
 
@@ -102,6 +111,52 @@ def test_batched_steps_vs_oracle(oracle, n_layers, P, B, S):
     np.testing.assert_array_equal(ch.counters.cpu().numpy(), ost.counters)
     assert int(ch.n_evals[0]) == lit
     assert (stat == 1).any()   # bounds rejections were exercised
+
+
+def test_batched_rotated_steps_vs_oracle(oracle):
+    """Rotated-frame proposals with covariance accumulation on every step, many steps per launch
+    (the settling order of the steps matters for cov_sum / params_prev)."""
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    rng = np.random.default_rng(7)
+    nl, P, B, S = 3, 16, 48, 50
+    NP = 2 * nl + 1
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
+    starts = []
+    while len(starts) < B:
+        x = oracle.sort_layers(rng.uniform(bounds[:, 0], bounds[:, 1]), nl)
+        if oracle.forward(x, nl, 1.75, periods)[0] == 0:
+            starts.append(x)
+    starts = np.array(starts)
+    obs = oracle.forward(starts[0], nl, 1.75, periods)[1] + 0.025 * rng.standard_normal(P)
+    noise = {"std": 0.025}
+    rot = np.stack([np.linalg.qr(rng.standard_normal((NP, NP)))[0] for _ in range(B)])
+    prob = DeviceProblem(nl, 1.75, periods, obs, "normal", noise, bounds)
+    ch = DeviceChains(prob, starts, 0.03)
+    assert int((ch.init_likelihood() != 0).sum()) == 0
+    dev = prob.device
+    ch.rot.copy_(torch.tensor(rot, device=dev))
+    _, ovel, _ = oracle.forward_batch(starts, nl, 1.75, periods)
+    ologL = np.array([oracle.loglik(obs, v, "normal", noise) for v in ovel])
+    ost = oracle.ChainState(starts, ologL, ovel, 0.03, bounds)
+    ost.rot[:] = rot
+    idx = rng.integers(0, NP, (S, B)).astype(np.int32)
+    cauchy = np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5))
+    u_acc = rng.uniform(size=(S, B))
+    out = ch.steps(torch.tensor(idx, device=dev), torch.tensor(cauchy, device=dev),
+                   torch.tensor(u_acc, device=dev), rotate=3)
+    acc = np.zeros((S, B), dtype=np.uint8)
+    for s in range(S):
+        acc[s], _, _ = oracle.mh_step(ost, idx[s], cauchy[s], u_acc[s], nl, 1.75, periods, obs,
+                                      "normal", noise, rotate=3)
+    np.testing.assert_array_equal(out["accepted"].cpu().numpy(), acc)
+    np.testing.assert_allclose(ch.m.cpu().numpy(), ost.m, rtol=1e-12)
+    np.testing.assert_array_equal(ch.n_cov.cpu().numpy(), ost.n_cov)
+    np.testing.assert_allclose(ch.cov_sum.cpu().numpy(), ost.cov_sum, rtol=1e-9, atol=1e-18)
+    np.testing.assert_allclose(ch.params_prev.cpu().numpy(), ost.params_prev, rtol=1e-12)
+    np.testing.assert_array_equal(ch.counters.cpu().numpy(), ost.counters)
+    assert acc.sum() > B and (ost.n_cov > 0).all()
 
 
 def test_rotation_trace(oracle):
