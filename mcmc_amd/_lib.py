@@ -69,6 +69,10 @@ def lib():
         raise MhdError(
             f"{LIB_PATH} not found: build the HIP library first (python -m mcmc_amd.build). "
             "There is no CPU fallback.")
+    # torch ships its own HIP runtime; it has to be the one already mapped when this library,
+    # which is linked against libamdhip64 too, is loaded (the other order leaves the process
+    # with two runtimes, and the second one finds no device)
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     pp, cp = ctypes.POINTER(Problem), ctypes.POINTER(Chains)
     L.mhd_abi_version.restype = ctypes.c_int

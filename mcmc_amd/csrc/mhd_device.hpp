@@ -383,9 +383,13 @@ __device__ __forceinline__ double scan_next(double& c1, int& idir, double clow, 
 // sign change lies in one of those cells -- the usual case -- three halvings are
 // already done.  Further rounds evaluate 64 scan abscissae, or the 63 nodes of a
 // 6-level tree.
+//
+// max_levels < 100 stops the halving after that many levels (a predictor's use): br[] then
+// receives the bracket {c1, c2, sign at c1} and c1io its midpoint.
 __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, double t1, double& c1io,
                                          double clow, double dc, double cm, double betmx,
-                                         bool ifirst, int& s1st, EvalCount& cnt)
+                                         bool ifirst, int& s1st, EvalCount& cnt,
+                                         int max_levels = 1000, double* br = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const double omega = TWOPI / t1;
@@ -447,7 +451,10 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
                 }
                 c1 = c2;
                 s1 = s2;
-                if (uni(c1 < cm || c1 >= betmx + dc)) return false;
+                if (uni(c1 < cm || c1 >= betmx + dc)) {
+                    if (br) br[2] = (double)s1;
+                    return false;
+                }
             }
         }
     }
@@ -473,13 +480,16 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
             }
             c1 = c2;
             s1 = s2;
-            if (uni(c1 < cm || c1 >= betmx + dc)) return false;
+            if (uni(c1 < cm || c1 >= betmx + dc)) {
+                    if (br) br[2] = (double)s1;
+                    return false;
+                }
         }
     }
 
     // ---- refine: pure interval halving ----
     double c3 = 0.0;
-    int nctrl = 2;
+    int nctrl = 2, levels = 0;
     bool done = false;
     if (pre_levels) {
         int node = 1;
@@ -495,7 +505,7 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
                 s1 = s3;
                 node = 2 * node + 1;
             }
-            if (uni(fabs(c1 - c2) <= 1.0e-6 * c1)) {
+            if (uni(fabs(c1 - c2) <= 1.0e-6 * c1) || ++levels >= max_levels) {
                 done = true;
                 break;
             }
@@ -533,12 +543,18 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
                 s1 = s3;
                 node = 2 * node + 1;
             }
-            if (uni(fabs(c1 - c2) <= 1.0e-6 * c1)) {
+            if (uni(fabs(c1 - c2) <= 1.0e-6 * c1) || ++levels >= max_levels) {
                 done = true;
                 break;
             }
             ++nctrl;
         }
+    }
+    if (br) {
+        br[0] = c1;
+        br[1] = c2;
+        br[2] = (double)s1;
+        c3 = 0.5 * (c1 + c2);
     }
     c1io = c3;
     return uni(c3 <= betmx);

@@ -25,9 +25,7 @@
 
 namespace mhd {
 
-constexpr int NPTS = 512;      // abscissae verified per pass (a long curve takes several passes)
 constexpr int MAX_REPAIRS = 3;  // then the wave-sequential search finishes the curve
-constexpr int NPTS_ROOM = 96;  // a new period is started only with this much room left
 
 struct PredictScratch {
     double lo[MAXP], hi[MAXP];    // root bracket per period (stage 1: one dc cell)
@@ -36,10 +34,11 @@ struct PredictScratch {
     signed char slo[MAXP], shi[MAXP];
     double fm[64];  // lane values of the current stage-1 round
     int fe[64];
-    double px[NPTS];         // abscissae consumed by the replay
-    unsigned char pk[NPTS];  // their period
-    signed char ps[NPTS];    // the sign the replay inferred there
-    unsigned short plit[MAXP];  // evaluations the sequential algorithm spends on the period
+    // what the replay did for each period (see replay_period)
+    double rstart[MAXP];
+    unsigned long long rbits[MAXP];
+    int rmeta[MAXP];
+    unsigned short roff[MAXP + 1];  // number of abscissae of the pass before the period's
     int trouble;  // repairs the last predicted curve needed (9: the predictor gave up)
 };
 
@@ -252,9 +251,63 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg,
     return P;
 }
 
+// ---- stage 1, period by period ------------------------------------------------
+// The same brackets from the sequential search itself, stopped after `levels` halvings of each
+// period (3: one round of the wave, 9: two) and continued from the bracket's midpoint.  Its
+// abscissae are within dc / 2^(levels+1) of the lattice the sequential algorithm will use, so
+// it follows that algorithm through densely spaced modes, where the windows of predict_coarse
+// lose it; it costs two to four times as many rounds.  The bracket ends carry signs only:
+// predict_refine evaluates them first.
+// kbeg > 0 continues from cprev = c[kbeg-1].  Returns like predict_coarse.
+__device__ MHD_NOINLINE int predict_stepwise(int wave, const double* t, int kbeg, int P,
+                                             double tscale, double dc, double cprev, int s1st_in,
+                                             int levels, EvalCount& cnt)
+{
+    PredictScratch& S = g_PS;
+    const LayerTable& T = g_T;
+    const int lane = threadIdx.x & 63;
+    const double cc = T.cc, betmx = T.betmx, cm = T.cc;
+    int s1st = s1st_in;
+    double cp = cprev;
+    EvalCount mine = {0, 0};
+    for (int k = kbeg; k < P; ++k) {
+        const bool ifirst = (k == 0);
+        double c1 = ifirst ? cc : cp - 1.5 * dc;
+        double br[3] = {0.0, 0.0, 0.0};
+        const bool ok = solve_period_wave(T, wave, t[k] / tscale, c1, ifirst ? cc : cm, dc, cm,
+                                          betmx, ifirst, s1st, mine, levels, br);
+        if (!ok) {
+            // the sequential search will fail here as well (unless the lattice decides otherwise)
+            if (lane == 0) {
+                S.lo[k] = 1.0e300;
+                S.hi[k] = 1.0e301;
+                S.slo[k] = (signed char)(int)br[2];
+                S.shi[k] = (signed char)(int)br[2];
+            }
+            cnt.exec += mine.exec;
+            wave_sync();
+            return k + 1;
+        }
+        const bool up = br[0] < br[1];
+        const int sa = (int)br[2];
+        if (lane == 0) {
+            S.lo[k] = up ? br[0] : br[1];
+            S.hi[k] = up ? br[1] : br[0];
+            S.slo[k] = (signed char)(up ? sa : -sa);
+            S.shi[k] = (signed char)(up ? -sa : sa);
+        }
+        cp = c1;
+    }
+    cnt.exec += mine.exec;
+    wave_sync();
+    return P;
+}
+
 // ---- stage 2 ----------------------------------------------------------------
-__device__ MHD_NOINLINE void predict_refine(int wave, const double* t, int kbeg,
-                                                         int P, double tscale, EvalCount& cnt)
+// eval_ends: the brackets come with signs only (predict_stepwise); the tracked values at their
+// ends are evaluated first.
+__device__ MHD_NOINLINE void predict_refine(int wave, const double* t, int kbeg, int P,
+                                            double tscale, EvalCount& cnt, bool eval_ends = false)
 {
     PredictScratch& S = g_PS;
     const int lane = threadIdx.x & 63;
@@ -271,6 +324,22 @@ __device__ MHD_NOINLINE void predict_refine(int wave, const double* t, int kbeg,
             ea = S.fae[k];
             eb = S.fbe[k];
             omega = TWOPI / (t[k] / tscale);
+        }
+        if (eval_ends) {
+            const bool real = active && a < 1.0e299;
+            if (real) {
+                const SecVal va = eval_secular(wave, omega, a);
+                const SecVal vb = eval_secular(wave, omega, b);
+                fa = va.m;
+                ea = va.e;
+                fb = vb.m;
+                eb = vb.e;
+            } else if (active) {
+                fa = (double)S.slo[k];
+                fb = (double)S.shi[k];
+                ea = eb = 0;
+            }
+            cnt.exec += 2ull * (unsigned long long)__popcll(__ballot(real));
         }
         const int sa = sgni(fa);
         int sb = sgni(fb);
@@ -319,93 +388,101 @@ __device__ MHD_NOINLINE void predict_refine(int wave, const double* t, int kbeg,
 }
 
 // ---- stage 3 ----------------------------------------------------------------
-struct Bracket {
-    double lo, hi;
-    int slo, shi;
-};
-
-// Sign of the secular function of period k at x: inferred from the bracket, or really
-// evaluated (by every lane, the result is uniform) when x falls inside the bracket.
-__device__ __forceinline__ int replay_sign(int wave, int k, double omega, double x, Bracket& br,
-                                           int& npts, int& nlit, unsigned long long& nexec)
+// getsol of period k with signs inferred from the bracket (same control flow and abscissa
+// arithmetic as solve_period_wave; every value is the same in all lanes).  Only the plain case:
+// a scan that meets neither the floor nor the ceiling, then halvings, no abscissa inside the
+// bracket.  What it did is kept as a summary -- start, direction, number of scan and halving
+// abscissae, the side taken at each halving -- from which replay_abscissa() regenerates any
+// abscissa it consumed.  Returns 1 (root found), 0 (the search ends above the ceiling) or
+// -1: not a plain case, nothing recorded.
+__device__ __forceinline__ int replay_period(int k, double& c1io, double clow, double dc,
+                                             double cm, double top, double betmx, bool ifirst,
+                                             int& s1st, int& count)
 {
-    ++nlit;
-    int s;
-    if (uni(x <= br.lo)) {
-        s = br.slo;
-    } else if (uni(x >= br.hi)) {
-        s = br.shi;
-    } else {
-        s = __builtin_amdgcn_readfirstlane(sgni(eval_secular(wave, omega, x).m));
-        nexec += 1;
-        if (s == br.slo) br.lo = x; else br.hi = x;
-        return s;
-    }
-    if (npts < NPTS) {  // every lane stores the same values
-        g_PS.px[npts] = x;
-        g_PS.pk[npts] = (unsigned char)k;
-        g_PS.ps[npts] = (signed char)s;
-    }
-    ++npts;  // beyond NPTS: overflow, detected by the caller
-    return s;
-}
-
-// getsol with inferred signs (same control flow and abscissa arithmetic as
-// solve_period_wave).  Every value here is the same in all lanes.
-__device__ __forceinline__ bool replay_period(int wave, int k, double t1, double& c1io,
-                                              double clow, double dc, double cm, double betmx,
-                                              bool ifirst, int& s1st, int& npts, int& nlit,
-                                              unsigned long long& nexec)
-{
-    Bracket br = {uniform_value(g_PS.lo[k]), uniform_value(g_PS.hi[k]),
-                  __builtin_amdgcn_readfirstlane((int)g_PS.slo[k]),
-                  __builtin_amdgcn_readfirstlane((int)g_PS.shi[k])};
-    const double omega = TWOPI / t1;
-    double c1 = c1io, c2;
-    int s1 = replay_sign(wave, k, omega, c1, br, npts, nlit, nexec);
-    if (ifirst) s1st = s1;
-    int idir = (ifirst || s1st * s1 >= 0) ? +1 : -1;
+    PredictScratch& S = g_PS;
+    const double lo = uniform_value(S.lo[k]), hi = uniform_value(S.hi[k]);
+    const int slo = __builtin_amdgcn_readfirstlane((int)S.slo[k]);
+    const int shi = __builtin_amdgcn_readfirstlane((int)S.shi[k]);
+    if (slo == 0 || shi == 0) return -1;
+    const double start = c1io;
+    double c1 = start, c2;
+    int s1 = (c1 <= lo) ? slo : shi;
+    const int sfirst = s1;
+    const bool upward = ifirst || s1st * s1 >= 0;
+    const double step = upward ? dc : -dc;
+    int ns = 1;
+    bool plain;
     for (;;) {
-        if (npts > NPTS) return false;
-        // one advance of the scan (scan_next with scalar branches)
-        for (;;) {
-            c2 = (idir > 0) ? c1 + dc : c1 - dc;
-            if (uni(c2 <= clow)) {
-                idir = +1;
-                c1 = clow;
-                continue;
-            }
+        c2 = c1 + step;
+        ++ns;
+        const int s2 = (c2 <= lo) ? slo : shi;
+        plain = (c2 > clow) && (ns <= 62);
+        if (uni(s1 != s2 || !plain || c2 < cm || c2 >= top)) {
+            plain = plain && (s1 != s2);
             break;
         }
-        const int s2 = replay_sign(wave, k, omega, c2, br, npts, nlit, nexec);
-        if (s1 != s2) break;
         c1 = c2;
         s1 = s2;
-        if (uni(c1 < cm || c1 >= betmx + dc)) return false;
     }
-    double c3 = 0.5 * (c1 + c2);
-    int s3 = replay_sign(wave, k, omega, c3, br, npts, nlit, nexec);
-    for (int nctrl = 2; nctrl < 100; ++nctrl) {
-        if (s3 * s1 < 0) {
-            c2 = c3;
-        } else {
-            c1 = c3;
-            s1 = s3;
-        }
-        if (uni(fabs(c1 - c2) <= 1.0e-6 * c1)) break;
+    if (!uni(plain)) return -1;
+    unsigned long long bits = 0;
+    int nh = 0;
+    double c3;
+    for (;;) {
         c3 = 0.5 * (c1 + c2);
-        s3 = replay_sign(wave, k, omega, c3, br, npts, nlit, nexec);
+        const int s3 = (c3 <= lo) ? slo : shi;
+        const bool left = s3 * s1 < 0;
+        bits |= left ? (1ull << nh) : 0ull;
+        ++nh;
+        c2 = left ? c3 : c2;
+        c1 = left ? c1 : c3;
+        s1 = left ? s1 : s3;
+        if (uni(fabs(c1 - c2) <= 1.0e-6 * c1)) break;
+        if (nh >= 40) return -1;
     }
+    // an abscissa inside the bracket would have become an end of [c1, c2]
+    if (!uni(fmin(c1, c2) <= lo && fmax(c1, c2) >= hi)) return -1;
+    if ((threadIdx.x & 63) == 0) {
+        S.rstart[k] = start;
+        S.rbits[k] = bits;
+        S.rmeta[k] = ns | (nh << 8) | ((int)upward << 16);
+    }
+    count = ns + nh;
+    if (ifirst) s1st = __builtin_amdgcn_readfirstlane(sfirst);
     c1io = c3;
-    return uni(c3 <= betmx);
+    return uni(c3 <= betmx) ? 1 : 0;
+}
+
+// The q-th abscissa replay_period consumed for period k (any lane, any k and q).
+__device__ __forceinline__ double replay_abscissa(int k, int q, double dc)
+{
+    const PredictScratch& S = g_PS;
+    const int meta = S.rmeta[k];
+    const int ns = meta & 255;
+    const double step = (meta >> 16) ? dc : -dc;
+    const unsigned long long bits = S.rbits[k];
+    double c1 = S.rstart[k], c2 = c1;
+    const int nscan = q < ns - 1 ? q : ns - 1;
+    for (int j = 0; j < nscan; ++j) {
+        c1 = c2;
+        c2 = c2 + step;
+    }
+    if (q < ns) return c2;
+    double c3 = 0.0;
+    for (int i = 0; i <= q - ns; ++i) {
+        c3 = 0.5 * (c1 + c2);
+        if ((bits >> i) & 1ull) c2 = c3; else c1 = c3;
+    }
+    return c3;
 }
 
 // ---- the curve ---------------------------------------------------------------
 // Fundamental-mode phase velocities c[0..P-1] (LDS) of the table in g_T, bit-identical to
 // phase_curve_wave(..., mode = 0, ...).  Returns MHD_ST_OK or MHD_ST_NOROOT.
-__device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int P,
-                                                               double tscale, double dc,
-                                                               double* c, EvalCount& cnt)
+// stepwise > 0: predict with predict_stepwise(levels = stepwise) instead of predict_coarse.
+__device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int P, double tscale,
+                                                  double dc, double* c, EvalCount& cnt,
+                                                  int stepwise)
 {
     const LayerTable& T = g_T;
     PredictScratch& S = g_PS;
@@ -413,7 +490,8 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
     const int lane = threadIdx.x & 63;
     dc = fabs(dc);
     PROF_T0
-    int nP = predict_coarse(wave, t, 0, P, tscale, dc, 0.0, 0, cnt);
+    int nP = stepwise ? predict_stepwise(wave, t, 0, P, tscale, dc, 0.0, 0, stepwise, cnt)
+                      : predict_coarse(wave, t, 0, P, tscale, dc, 0.0, 0, cnt);
     PROF_ADD(0)
     S.trouble = (nP < 0) ? 9 : 0;
     if (nP < 0) {
@@ -421,20 +499,17 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
         PROF_ADD(5)
         return r;
     }
-    predict_refine(wave, t, 0, nP, tscale, cnt);
+    predict_refine(wave, t, 0, nP, tscale, cnt, stepwise > 0);
     PROF_ADD(1)
 
     const double cc = T.cc, betmx = T.betmx, cm = T.cc;
     int s1st = 0, kstart = 0, repairs = 0;
     for (;;) {
-        // replay periods kstart..kend-1 (c[kstart-1] and s1st are exact); a pass ends when the
-        // abscissa list is nearly full
-        int npts = 0, kfail = -1, kend = kstart;
-        unsigned long long nexec = 0;
+        // replay periods kstart..kend-1 (c[kstart-1] and s1st are exact); period kplain, if
+        // any, is not a plain case and ends the pass
+        int npts = 0, kfail = -1, kplain = -1, kend = kstart;
         double c1 = cc;
-        bool overflow = false;
         for (int k = kstart; k < nP; ++k) {
-            if (k > kstart && npts > NPTS - NPTS_ROOM) break;
             const bool ifirst = (k == 0);
             double clow;
             if (ifirst) {
@@ -444,35 +519,33 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
                 clow = cm;
                 c1 = uniform_value(c[k - 1]) - 1.5 * dc;
             }
-            int nlit = 0;
-            const int npts0 = npts;
-            const int s1st0 = s1st;
-            const bool ok = replay_period(wave, k, t[k] / tscale, c1, clow, dc, cm, betmx, ifirst,
-                                          s1st, npts, nlit, nexec);
-            if (npts > NPTS) {
-                // this period did not fit: verify the earlier ones first, or (alone) give it to
-                // the wave-sequential search
-                npts = npts0;
-                s1st = s1st0;
-                overflow = (k == kstart);
+            int count = 0;
+            const int r = replay_period(k, c1, clow, dc, cm, betmx + dc, betmx, ifirst, s1st, count);
+            if (r < 0) {
+                kplain = k;
                 break;
             }
-            if (lane == 0) S.plit[k] = (unsigned short)nlit;
+            if (lane == 0) S.roff[k] = (unsigned short)npts;
+            npts += count;
             kend = k + 1;
-            if (!ok) {
+            if (r == 0) {
                 kfail = k;
                 break;
             }
             c[k] = c1;
         }
-        cnt.exec += nexec;
+        if (lane == 0) S.roff[kend] = (unsigned short)npts;
         wave_sync();
         PROF_ADD(2)
-        if (overflow) {
-            const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
-            PROF_ADD(4)
-            return r;
-        }
+        // the period abscissa i of this pass belongs to
+        auto period_of = [&](int i) -> int {
+            int a = kstart, b = kend - 1;
+            while (a < b) {
+                const int mid = (a + b + 1) >> 1;
+                if ((int)S.roff[mid] <= i) a = mid; else b = mid - 1;
+            }
+            return a;
+        };
         // verify: really evaluate every abscissa the replay consumed
         int vbeg = 0, klit = kstart;  // first unverified abscissa; first period not yet counted
         bool again = false;           // replay again from kstart
@@ -483,9 +556,11 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
                 const bool act = i < npts;
                 bool bad = false;
                 if (act) {
-                    const int k = S.pk[i];
+                    const int k = period_of(i);
+                    const double x = replay_abscissa(k, i - (int)S.roff[k], dc);
+                    const int want = (x <= S.lo[k]) ? (int)S.slo[k] : (int)S.shi[k];
                     const double omega = TWOPI / (t[k] / tscale);
-                    bad = sgni(eval_secular(wave, omega, S.px[i]).m) != (int)S.ps[i];
+                    bad = sgni(eval_secular(wave, omega, x).m) != want;
                 }
                 const unsigned long long mask = __ballot(bad);
                 cnt.exec += (unsigned long long)__popcll(__ballot(act));
@@ -497,8 +572,8 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             PROF_ADD(3)
             if (first_bad == npts) break;
             // periods before the first wrong sign are exact
-            const int kbad = S.pk[first_bad];
-            for (int k = klit; k < kbad; ++k) cnt.lit += S.plit[k];
+            const int kbad = period_of(first_bad);
+            for (int k = klit; k < kbad; ++k) cnt.lit += (int)S.roff[k + 1] - (int)S.roff[k];
             klit = kbad + 1;
 #ifdef MHD_PROFILE
             if (lane == 0) { atomicAdd(&g_prof[6], 1ull); if (blockIdx.x < 1024) g_blk[blockIdx.x * 8 + 6] += 1; }
@@ -526,19 +601,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             if (uni(cr == cold)) {
                 // same answer: the replay of the later periods stands; verify on from the
                 // first abscissa of the next period
-                int nb = npts;
-                for (int base = first_bad + 1; base < npts; base += 64) {
-                    const int i = base + lane;
-                    const unsigned long long mk = __ballot(i < npts && (int)S.pk[i] > kbad);
-                    if (mk) {
-                        nb = base + (int)__ffsll((long long)mk) - 1;
-                        break;
-                    }
-                }
-                vbeg = nb;
-#ifdef MHD_PROFILE
-                if (lane == 0) atomicAdd(&g_prof[11], 1ull);
-#endif
+                vbeg = (int)S.roff[kbad + 1];
                 continue;
             }
             kstart = kbad + 1;
@@ -546,36 +609,44 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             const double plo = uniform_value(S.lo[kbad]), phi = uniform_value(S.hi[kbad]);
             if (kbad < nP - 1 && uni(cr >= plo - 2.0e-6 * cr && cr <= phi + 2.0e-6 * cr)) {
                 // same root on another lattice: the predictions for the later periods stand
-#ifdef MHD_PROFILE
-                if (lane == 0) atomicAdd(&g_prof[12], 1ull);
-#endif
                 break;
             }
-#ifdef MHD_PROFILE
-            if (lane == 0) atomicAdd(&g_prof[13], 1ull);
-#endif
             // the sequential search moved to another branch than the predictor's: predict the
             // remaining periods again, continuing from the root it found
-            nP = predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, cnt);
+            nP = stepwise ? predict_stepwise(wave, t, kstart, P, tscale, dc, cr, s1st, stepwise, cnt)
+                          : predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, cnt);
             PROF_ADD(0)
             if (nP < 0) {
                 const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
                 PROF_ADD(5)
                 return r;
             }
-            predict_refine(wave, t, kstart, nP, tscale, cnt);
+            predict_refine(wave, t, kstart, nP, tscale, cnt, stepwise > 0);
             PROF_ADD(1)
             break;
         }
         if (again) continue;
-        for (int k = klit; k < kend; ++k) cnt.lit += S.plit[k];
+        for (int k = klit; k < kend; ++k) cnt.lit += (int)S.roff[k + 1] - (int)S.roff[k];
 #ifdef MHD_PROFILE
         if (lane == 0 && (kend >= nP || kfail >= 0)) atomicAdd(&g_prof[8], 1ull);
 #endif
         if (kfail >= 0) return MHD_ST_NOROOT;
-        if (kend < nP) {  // next pass
-            kstart = kend;
-            continue;
+        if (kplain >= 0) {
+            // not a plain case (floor, ceiling, an abscissa inside the bracket): this period by
+            // the wave-sequential search, then on with the predictions for the later ones
+            const bool ifirst = (kplain == 0);
+            double cr = ifirst ? cc : uniform_value(c[kplain - 1]) - 1.5 * dc;
+            const bool ok = solve_period_wave(T, wave, t[kplain] / tscale, cr, ifirst ? cc : cm,
+                                              dc, cm, betmx, ifirst, s1st, cnt);
+            PROF_ADD(4)
+            if (!ok) return MHD_ST_NOROOT;
+            c[kplain] = cr;
+            wave_sync();
+            kstart = kplain + 1;
+            if (kstart >= P) return MHD_ST_OK;
+            if (kstart < nP) continue;
+            // fall through: the predictions end here
+            nP = kstart;
         }
         if (nP == P) return MHD_ST_OK;
         // the predictor saw no root for period nP-1 but the search found one: go on
@@ -588,16 +659,17 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
 // forward_model with the period-parallel curve where it applies (fundamental mode).
 __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode, int itype,
                                         const double* t, int P, double dc, double dt,
-                                        double* vel, double* scratch, EvalCount& cnt)
+                                        double* vel, double* scratch, EvalCount& cnt,
+                                        int stepwise = 0)
 {
-    if (mode != 0 || P > 255)
+    if (mode != 0)
         return forward_wave(T, wave, mode, itype, t, P, dc, dt, vel, scratch, cnt);
-    if (itype == MHD_PHASE) return phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt);
+    if (itype == MHD_PHASE) return phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt, stepwise);
     double* c1 = scratch;
     double* c2 = scratch + P;
-    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt);
+    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt, stepwise);
     if (st != MHD_ST_OK) return st;
-    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt);
+    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt, stepwise);
     if (st != MHD_ST_OK) return st;
     for (int k = 0; k < P; ++k) {
         if (c1[k] > 0.0 && c2[k] > 0.0) {

@@ -1,0 +1,33 @@
+import os, sys, ctypes, json
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import mcmc_amd._lib as L
+L.LIB_PATH=os.path.join(ROOT,'mcmc_amd','lib','libmcmc_amd_prof.so')
+import torch; torch.cuda.init(); torch.zeros(1,device="cuda"); lib=L.lib()
+sys.argv=['bench.py','--steps','500','--warmup','250','--no-cpu']+sys.argv[1:]
+import runpy, io, contextlib
+import numpy as np
+bb=(ctypes.c_ulonglong*8192)()
+lib.mhd_debug_blk(bb,1)
+buf=io.StringIO()
+with contextlib.redirect_stdout(buf):
+    runpy.run_path(os.path.join(ROOT,'bench.py'), run_name='__main__')
+d=json.loads(buf.getvalue())
+print("value %.0f ms/step %.3f exec/lit %.2f"%(d['value'], d['ms_per_step'], d['roofline']['executed_evals_per_launch']/d['roofline']['algorithmic_evals_per_launch']))
+tt=(ctypes.c_ulonglong*4096)()
+lib.mhd_debug_times(tt)
+a=np.array(list(tt),dtype=np.float64).reshape(2048,2)[:1024]
+t0=a[:,0].min()
+st=(a[:,0]-t0)/100.0; en=(a[:,1]-t0)/100.0
+dur=en-st
+print("last launch (250 steps): start us max %.0f | per-chain us/step: min %.0f p10 %.0f median %.0f p90 %.0f p99 %.0f max %.0f mean %.0f"%(st.max(), *(np.percentile(dur,q)/250 for q in (0,10,50,90,99,100)), dur.mean()/250))
+print("duration histogram us/step:", np.histogram(dur/250,bins=12))
+lib.mhd_debug_blk(bb,0)
+raw=np.array(list(bb),dtype=np.uint64).reshape(1024,8)
+b=np.zeros((1024,8)); b[:,0]=(raw[:,7]>>np.uint64(40)); b[:,1]=((raw[:,7]>>np.uint64(20))&np.uint64(0xFFFFF)); b[:,2]=(raw[:,7]&np.uint64(0xFFFFF)); cyc=raw[:,:7].astype(np.float64)
+nst=750.0
+print("per chain over 750 steps: rounds/step mean %.3f, forwards/step %.3f, sequential-search share %.3f"%(b[:,0].mean()/nst, b[:,1].mean()/nst, b[:,2].sum()/b[:,1].sum()))
+order=np.argsort(dur)
+for label,idxs in (("fastest 3",order[:3]),("median 3",order[510:513]),("slowest 10",order[-10:])):
+    print(label)
+    for i in idxs:
+        print("  blk %4d %.0f us/step | rounds/step %.3f forwards/step %.3f seq %.2f step %.2f | kcycles/fwd coarse %.0f refine %.0f replay %.0f verify %.0f repair %.0f giveup %.0f mism/fwd %.2f"%(i,dur[i]/250,b[i,0]/nst,b[i,1]/nst,b[i,2]/max(b[i,1],1),cyc[i,6]/max(b[i,1],1),*(cyc[i,j]/1e3/max(b[i,1],1) for j in range(6)),cyc[i,6]/max(b[i,1],1)))
