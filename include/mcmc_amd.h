@@ -22,13 +22,14 @@
 #ifndef MCMC_AMD_H
 #define MCMC_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define MHD_ABI_VERSION 1
+#define MHD_ABI_VERSION 2
 
 #define MHD_OK 0
 #define MHD_EINVAL (-22) /* bad argument (size beyond a compiled limit, NULL pointer) */
@@ -100,7 +101,17 @@ typedef struct mhd_chains {
     int64_t *counters_ind; /* device [B,NP,5] per-parameter counters
                             (individual_acceptance, model.py:46-58), or NULL  */
     const double *beta;  /* device [B] tempering exponent, or NULL for 1      */
+    void *sched;         /* device, mhd_sched_bytes(B) bytes, or NULL: scratch the
+                            library keeps between calls of mhd_mh_steps (what each
+                            chain's steps cost last time); zero it once, before the
+                            first call.  With it, the chains that take longest get
+                            four candidates in flight instead of two and the chains
+                            are started longest first.  Results do not depend on it;
+                            no counterpart in the reference                       */
 } mhd_chains_t;
+
+/* Size of mhd_chains_t.sched for B chains. */
+size_t mhd_sched_bytes(int32_t B);
 
 int mhd_abi_version(void);
 const char *mhd_last_error(void);

@@ -18,13 +18,14 @@ PHASE, GROUP = 0, 1
 NORMAL, ASYM_LAPLACE = 0, 1
 ROT_ACCUMULATE, ROT_FRAME = 1, 2
 MAX_LAYERS, MAX_PERIODS = 15, 128
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = (
     "mhd_abi_version",
     "mhd_last_error",
     "mhd_set_search",
     "mhd_set_candidates",
+    "mhd_sched_bytes",
     "mhd_secular_batch",
     "mhd_forward_batch",
     "mhd_loglik_batch",
@@ -50,6 +51,7 @@ class Chains(ctypes.Structure):
         ("m", c_void_p), ("logL", c_void_p), ("pred", c_void_p), ("params_prev", c_void_p),
         ("width", c_void_p), ("rot", c_void_p), ("cov_sum", c_void_p), ("n_cov", c_void_p),
         ("counters", c_void_p), ("counters_ind", c_void_p), ("beta", c_void_p),
+        ("sched", c_void_p),
     ]
 
 
@@ -81,6 +83,8 @@ def lib():
     L.mhd_last_error.argtypes = []
     L.mhd_set_search.argtypes = [c_int32]
     L.mhd_set_candidates.argtypes = [c_int32]
+    L.mhd_sched_bytes.argtypes = [c_int32]
+    L.mhd_sched_bytes.restype = ctypes.c_size_t
     L.mhd_secular_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                     c_void_p, c_void_p]
     L.mhd_forward_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]

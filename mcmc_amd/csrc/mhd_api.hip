@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64) MHD_REGS void secular_kernel(mhd_problem_t p, c
                                                      const double* c, int N, double* delta)
 {
     // one wave per query keeps the table code identical to the other kernels
-    LayerTable& T = g_Tw[threadIdx.x >> 6];
+    LayerTable& T = g_T;
     __shared__ double m[MAXNP];
     const int q = blockIdx.x;
     if (q >= N) return;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) MHD_REGS void forward_kernel(mhd_problem_t p, c
                                                      double* vel, int32_t* status,
                                                      unsigned long long* n_evals, int search)
 {
-    LayerTable& T = g_Tw[threadIdx.x >> 6];
+    LayerTable& T = g_T;
     __shared__ double m[MAXNP];
     __shared__ double t[MAXP];
     __shared__ double out[MAXP];
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     int32_t* status, int hist_every, double* hist_m, double* hist_logL, double* hist_pred,
     unsigned long long* n_evals, int search)
 {
-    LayerTable& T = g_Tw[threadIdx.x >> 6];
+    LayerTable& T = g_T;
     __shared__ double m[MAXNP];     // current parameters
     __shared__ double mn[MAXNP];    // normalised current parameters
     __shared__ double test[MAXNP];  // proposal
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred,
                                        scratch, cnt, policy.stepwise());
                 if (search == 2)
-                    policy.update(1, __builtin_amdgcn_readfirstlane(g_PSw[0].trouble) >= 2);
+                    policy.update(1, __builtin_amdgcn_readfirstlane(g_PS.trouble) >= 2);
             } else {
                 st = forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred, scratch,
                                   cnt);
@@ -385,50 +385,179 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     }
 }
 
-// The same chain of Metropolis-Hastings steps with two candidates in flight: a workgroup of two
-// waves per chain.  From the current state, wave 0 takes the first proposal that passes the
-// bounds (steps before it are rejections that cost nothing) and wave 1 the next one after it;
-// both run the forward model at the same time.  The steps are then settled strictly in order:
-// wave 1's result is used only if wave 0's candidate was rejected, because only then did its
-// proposal start from the state the sequential chain has at that step.  States, likelihoods,
-// counters and the draw each step consumes are those of the one-candidate kernel.
-__global__ __launch_bounds__(128) MHD_REGS void mh_steps_pair_kernel(
+// ---- cost-aware launch schedule ---------------------------------------------
+// mhd_chains_t.sched, kept between calls: what a step of each chain cost last time (ticks of
+// the 100 MHz clock, scaled to one candidate in flight; 0 = not known yet), and what the next
+// launch is made from: the chains in order of decreasing cost and the number n4 of chains at
+// the head of that order that run with four candidates in flight.  Somewhat more than 2 * n4
+// chains at its tail run with one candidate, all others with two, so a launch keeps at most two
+// waves per chain on average and the expensive chains finish closer to the others.
+constexpr int SCHED_MAX_CHAINS = 4096;  // one workgroup sorts them in LDS
+constexpr int SCHED_SPARE = 8;           // workgroup places left free in a scheduled launch
+__device__ __constant__ float SCHED_CONSUMED[5] = {0.0f, 1.0f, 1.65f, 2.07f, 2.35f};
+
+struct SchedView {
+    float* cost;  // [B]
+    int* n4;      // [0] n4, [1] number of split workgroups (+ padding)
+    int* order;   // [B]
+};
+
+__host__ __device__ inline int sched_cap4(int B) { return B / 16 > 0 ? B / 16 : 1; }
+
+__host__ __device__ inline SchedView sched_view(void* buf, int B)
+{
+    SchedView v;
+    v.cost = (float*)buf;
+    v.n4 = (int*)(v.cost + B);
+    v.order = v.n4 + 4;
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B)
+{
+    __shared__ float key[SCHED_MAX_CHAINS];
+    __shared__ int val[SCHED_MAX_CHAINS];
+    __shared__ int unknown;
+    const SchedView v = sched_view(buf, B);
+    int n = 1;
+    while (n < B) n <<= 1;
+    if (threadIdx.x == 0) unknown = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float c = i < B ? v.cost[i] : -1.0f;
+        key[i] = c;
+        val[i] = i < B ? i : -1;
+        if (i < B && !(c > 0.0f)) unknown = 1;
+    }
+    __syncthreads();
+    // bitonic sort, descending by cost (ties: by chain index, so that the order is definite)
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool desc = (i & k) == 0;
+                    const float a = key[i], b = key[l];
+                    const int ia = val[i], ibv = val[l];
+                    const bool a_first = a > b || (a == b && ia < ibv);
+                    if (desc != a_first) {
+                        key[i] = b;
+                        key[l] = a;
+                        val[i] = ibv;
+                        val[l] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // four candidates for the chains that would otherwise finish later than the most expensive
+    // one does with four -- as long as the chains that give up a candidate for it still finish
+    // earlier than that.  A few more chains than needed give one up: workgroups do not pack
+    // perfectly, and one that has to wait for room starts when the first chains are done.
+    if (threadIdx.x == 0) {
+        int n4 = 0, nsplit = 0;
+        if (!unknown) {
+            const float with4 = key[0] / SCHED_CONSUMED[4];
+            const int cap = sched_cap4(B);
+            while (n4 < cap && key[n4] / SCHED_CONSUMED[2] > with4) {
+                const int ns = n4 + 1 + SCHED_SPARE;
+                if (n4 + 1 + 2 * ns >= B) break;
+                const float target = fmaxf(with4, key[n4 + 1] / SCHED_CONSUMED[2]);
+                if (key[B - 2 * ns] > target) break;
+                ++n4;
+                nsplit = ns;
+            }
+        }
+        v.n4[0] = n4;
+        v.n4[1] = nsplit;
+    }
+    for (int i = threadIdx.x; i < B; i += blockDim.x) v.order[i] = val[i];
+}
+
+// The same chain of Metropolis-Hastings steps with several candidates in flight: NW waves per
+// chain.  From the current state, wave w takes the (w+1)-th proposal that passes the bounds
+// (steps without one are rejections that cost nothing); all run the forward model at the same
+// time.  The steps are then settled strictly in order: a wave's result is used only if the
+// candidates before it were all rejected, because only then did its proposal start from the
+// state the sequential chain has at that step.  States, likelihoods, counters and the draw each
+// step consumes are those of the one-candidate kernel.
+//
+// scheduled: the workgroups take their chains from the launch schedule (see SchedView): the
+// NW = 4 kernel the n4 most expensive chains, the NW = 2 kernel all others -- the 2 * n4
+// cheapest ones two to a workgroup, each with ONE wave and one candidate ("split" workgroups,
+// whose two waves never meet in a barrier).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     mhd_problem_t p, mhd_chains_t ch, int B, int S, const int32_t* idx, const double* cauchy,
     const double* u_acc, double Temp, int rotate, uint8_t* accepted, int32_t* status,
     int hist_every, double* hist_m, double* hist_logL, double* hist_pred,
-    unsigned long long* n_evals, int search)
+    unsigned long long* n_evals, int search, int scheduled)
 {
-    __shared__ double m[MAXNP];   // current parameters
-    __shared__ double mn[MAXNP];  // normalised current parameters
-    __shared__ double lo[MAXNP], hi[MAXNP], rg[MAXNP], wid[MAXNP];
+    constexpr int NG = (NW == 2) ? 2 : 1;  // chains a workgroup can hold
+    __shared__ double lo[MAXNP], hi[MAXNP], rg[MAXNP];
     __shared__ double t[MAXP];
-    __shared__ double pred[MAXP];
-    __shared__ double test[NWAVE][MAXNP];  // candidate of each wave
-    __shared__ double tmp[NWAVE][MAXNP];
-    __shared__ double newpred[NWAVE][MAXP];
-    __shared__ double scratch[NWAVE][2 * MAXP];
-    __shared__ int r_step[NWAVE], r_st[NWAVE], r_trouble[NWAVE];
-    __shared__ double r_logL[NWAVE];
-    __shared__ unsigned long long r_lit[NWAVE];
+    __shared__ double m_[NG][MAXNP];    // current parameters
+    __shared__ double mn_[NG][MAXNP];   // normalised current parameters
+    __shared__ double wid_[NG][MAXNP];
+    __shared__ double pred_[NG][MAXP];
+    __shared__ double test[NW][MAXNP];  // candidate of each wave
+    __shared__ double tmp[NW][MAXNP];
+    __shared__ double newpred[NW][MAXP];
+    __shared__ double scratch[NW][2 * MAXP];
+    __shared__ int r_step[NW], r_st[NW], r_trouble[NW];
+    __shared__ double r_logL[NW];
+    __shared__ unsigned long long r_lit[NW];
 
-    const int ib = blockIdx.x;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nl = p.n_layers, NP = 2 * nl + 1, P = p.n_periods;
-    LayerTable& T = g_Tw[w];
+    // the chain of this wave: the workgroup's own index, or its place in the launch schedule
+    int ib = blockIdx.x;
+    bool split = false;
+    if (scheduled) {
+        const SchedView sv = sched_view(ch.sched, B);
+        const int n4 = sv.n4[0];
+        if (NW == 4) {
+            if (ib >= n4) return;
+        } else {
+            // first the split workgroups (which run longest), then the others by decreasing
+            // cost: should a few workgroups have to wait for room, they are the cheapest
+            const int nsplit = sv.n4[1];
+            if (ib >= B - n4 - nsplit) return;
+            split = ib < nsplit;
+            ib = split ? B - 2 * nsplit + 2 * ib + w : n4 + ib - nsplit;
+        }
+        ib = sv.order[ib];
+    }
+    const int g = split ? w : 0;    // chain slot of this wave in the workgroup
+    const int w0 = split ? w : 0;   // first wave of this wave's chain
+    const int nw = split ? 1 : NW;  // waves (= candidates in flight) of this wave's chain
+    const bool writer = (w == w0);
+    auto group_sync = [&]() {
+        if (split) wave_sync(); else __syncthreads();
+    };
+    double* m = m_[g];
+    double* mn = mn_[g];
+    double* wid = wid_[g];
+    double* pred = pred_[g];
 
-    if (w == 0) {
+    const long long t_begin = wall_clock64();
+    const int nl = p.n_layers, NP = 2 * nl + 1, P = p.n_periods;
+    LayerTable& T = g_T;
+
+    if (threadIdx.x < NP) {
+        lo[threadIdx.x] = p.bounds[3 * threadIdx.x];
+        hi[threadIdx.x] = p.bounds[3 * threadIdx.x + 1];
+        rg[threadIdx.x] = p.bounds[3 * threadIdx.x + 2];
+    }
+    for (int k = threadIdx.x; k < P; k += 64 * NW) t[k] = p.periods[k];
+    __syncthreads();  // the only barrier the waves of a split workgroup share
+    if (writer) {
         if (lane < NP) {
             m[lane] = ch.m[(size_t)ib * NP + lane];
-            lo[lane] = p.bounds[3 * lane];
-            hi[lane] = p.bounds[3 * lane + 1];
-            rg[lane] = p.bounds[3 * lane + 2];
             wid[lane] = ch.width[(size_t)ib * NP + lane];
             mn[lane] = (m[lane] - lo[lane]) / rg[lane];
         }
-        for (int k = lane; k < P; k += 64) {
-            t[k] = p.periods[k];
-            pred[k] = ch.pred[(size_t)ib * P + k];
-        }
+        for (int k = lane; k < P; k += 64) pred[k] = ch.pred[(size_t)ib * P + k];
     }
     double logL = ch.logL[ib];
     const double beta = ch.beta ? ch.beta[ib] : 1.0;
@@ -440,17 +569,17 @@ __global__ __launch_bounds__(128) MHD_REGS void mh_steps_pair_kernel(
     SearchPolicy policy = {search == 2 ? 0 : 3, 0};
 #ifdef MHD_PROFILE
     const long long k_w0 = wall_clock64();
-    if (threadIdx.x == 0 && ib < 2048) g_times[2 * ib] = (unsigned long long)k_w0;
+    if (writer && lane == 0 && ib < 2048) g_times[2 * ib] = (unsigned long long)k_w0;
 #endif
-    __syncthreads();
+    group_sync();
 
-    // everything one step leaves behind besides the state itself (wave 0 writes)
+    // everything one step leaves behind besides the state itself (the chain's first wave writes)
     auto book = [&](int j, int st, int acc) {
         c_acc += acc;
         c_rej += !acc;
         c_bnd += (st == MHD_ST_BOUNDS);
         c_fm += (st >= MHD_ST_NOROOT);
-        if (w != 0) return;
+        if (!writer) return;
         if (lane == 0) {
             if (ch.counters_ind) {
                 const int kk = idx[(size_t)j * B + ib];
@@ -473,9 +602,10 @@ __global__ __launch_bounds__(128) MHD_REGS void mh_steps_pair_kernel(
     };
     // the start of step j: update_covariance_matrix sees the state the step starts from
     auto begin_step = [&]() {
-        if ((rotate & MHD_ROT_ACCUMULATE) && w == 0) cov_accumulate_wave(ch, ib, NP, mn, tmp[0], lane);
+        if ((rotate & MHD_ROT_ACCUMULATE) && writer)
+            cov_accumulate_wave(ch, ib, NP, mn, tmp[w0], lane);
     };
-    // accept test of a candidate (model.py:449-467) and, if it passes, the move
+    // accept test of the candidate of wave c (model.py:449-467) and, if it passes, the move
     auto settle = [&](int c, int j) -> int {
         const int st = r_st[c];
         int acc = 0;
@@ -486,7 +616,7 @@ __global__ __launch_bounds__(128) MHD_REGS void mh_steps_pair_kernel(
             if (ch.beta) dl = beta * dl;
             acc = u_acc[(size_t)j * B + ib] <= exp(dl);
             if (acc) {
-                if (w == 0) {
+                if (writer) {
                     if (lane < NP) {
                         ch.params_prev[(size_t)ib * NP + lane] = mn[lane];
                         m[lane] = test[c][lane];
@@ -504,13 +634,14 @@ __global__ __launch_bounds__(128) MHD_REGS void mh_steps_pair_kernel(
 
     int s = 0;
     while (s < S) {
-        // ---- this wave's candidate: the (w+1)-th proposal from step s on that passes the bounds
+        // ---- this wave's candidate: the (w-w0+1)-th proposal from step s on that passes the
+        // bounds
         int jc = S, found = 0;
         for (int j = s; j < S; ++j) {
             const int kk = idx[(size_t)j * B + ib];
             const double cz = cauchy[(size_t)j * B + ib];
             if (propose_wave(frame, mn, kk, cz, test[w], tmp[w], lane) == MHD_ST_OK &&
-                ++found == w + 1) {
+                ++found == w - w0 + 1) {
                 jc = j;
                 break;
             }
@@ -523,7 +654,7 @@ __global__ __launch_bounds__(128) MHD_REGS void mh_steps_pair_kernel(
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
                                        scratch[w], cnt, policy.stepwise());
-                trouble = __builtin_amdgcn_readfirstlane(g_PSw[w].trouble);
+                trouble = __builtin_amdgcn_readfirstlane(g_PS.trouble);
             } else {
                 st = forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
                                   scratch[w], cnt);
@@ -539,56 +670,54 @@ __global__ __launch_bounds__(128) MHD_REGS void mh_steps_pair_kernel(
             r_logL[w] = lnew;
             r_lit[w] = cnt.lit;
         }
-        __syncthreads();
+        group_sync();
 
-        // ---- settle the steps in order (both waves follow; wave 0 writes)
-        const int jA = r_step[0], jB = r_step[1];
-        for (int j = s; j < jA; ++j) {  // jA <= S
-            begin_step();
-            book(j, MHD_ST_BOUNDS, 0);
-        }
-        s = jA;
+        // ---- settle the steps in order (all waves of the chain follow; the first one writes)
         int ran = 0;
-        if (jA < S) {
-            begin_step();
-            lit += r_lit[0];
-            ran = 1 + (jB < S);
-            s = jA + 1;
-            if (!settle(0, jA)) {
-                // wave 1's candidate started from the state that still holds
-                for (int j = jA + 1; j < jB; ++j) {  // jB <= S
-                    begin_step();
-                    book(j, MHD_ST_BOUNDS, 0);
-                }
-                s = jB;
-                if (jB < S) {
-                    begin_step();
-                    lit += r_lit[1];
-                    settle(1, jB);
-                    s = jB + 1;
-                }
+        bool trouble2 = false;
+        for (int c = w0; c < w0 + nw; ++c) {
+            ran += (r_step[c] < S);
+            trouble2 |= r_trouble[c] >= 2;
+        }
+        for (int c = w0; c < w0 + nw; ++c) {
+            const int j = r_step[c];  // <= S, increasing with c
+            for (; s < j; ++s) {
+                begin_step();
+                book(s, MHD_ST_BOUNDS, 0);
             }
+            if (j >= S) break;
+            begin_step();
+            lit += r_lit[c];
+            s = j + 1;
+            // an acceptance: the later candidates started from a state that no longer holds
+            if (settle(c, j)) break;
         }
 #ifdef MHD_PROFILE
-        if (threadIdx.x == 0 && ib < 1024) {
-            g_blk[ib * 8 + 7] += 1ull << 40;                      // rounds
-            g_blk[ib * 8 + 7] += (unsigned long long)ran << 20;                    // forwards run
-            g_blk[ib * 8 + 7] += (policy.level == 3) ? ran : 0;  // of which wave-sequential
+        if (writer && lane == 0 && ib < 1024) {
+            g_blk[ib * 8 + 7] += 1ull << 40;                       // rounds
+            g_blk[ib * 8 + 7] += (unsigned long long)ran << 20;    // forwards run
+            g_blk[ib * 8 + 7] += (policy.level == 3) ? ran : 0;    // of which wave-sequential
         }
 #endif
-        if (search == 2) policy.update(ran, r_trouble[0] >= 2 || r_trouble[1] >= 2);
-        __syncthreads();
+        if (search == 2) policy.update(ran, trouble2);
+        group_sync();
     }
 
 #ifdef MHD_PROFILE
-    if (threadIdx.x == 0 && ib < 2048) g_times[2 * ib + 1] = (unsigned long long)wall_clock64();
+    if (writer && lane == 0 && ib < 2048) g_times[2 * ib + 1] = (unsigned long long)wall_clock64();
 #endif
-    if (w == 0) {
+    if (writer && lane == 0 && ch.sched && B <= SCHED_MAX_CHAINS) {
+        float* cost = sched_view(ch.sched, B).cost;
+        const float now = (float)(wall_clock64() - t_begin) * SCHED_CONSUMED[nw] / (float)S;
+        const float old = cost[ib];
+        cost[ib] = old > 0.0f ? 0.5f * (old + now) : now;
+    }
+    if (writer) {
         if (lane < NP) ch.m[(size_t)ib * NP + lane] = m[lane];
         for (int k = lane; k < P; k += 64) ch.pred[(size_t)ib * P + k] = pred[k];
     }
     if (lane == 0) {
-        if (w == 0) {
+        if (writer) {
             ch.logL[ib] = logL;
             int64_t* c5 = ch.counters + (size_t)ib * 5;
             c5[0] += c_acc;
@@ -606,7 +735,49 @@ __global__ __launch_bounds__(128) MHD_REGS void mh_steps_pair_kernel(
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+namespace {
+
+// A second stream per device for the two-candidate kernel of a scheduled launch, with the
+// events that tie it to the caller's stream.  Created at the first use, kept until the process
+// ends.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ready = false;
+};
+SideStream g_side[32];
+
+SideStream* side_stream()
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 32) {
+        hip_fail(e, "hipGetDevice");
+        return nullptr;
+    }
+    SideStream& sd = g_side[dev];
+    if (!sd.ready) {
+        e = hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            hip_fail(e, "side stream");
+            return nullptr;
+        }
+        sd.ready = true;
+    }
+    return &sd;
+}
+
+}  // namespace
+
 extern "C" {
+
+size_t mhd_sched_bytes(int32_t B)
+{
+    if (B < 0) B = 0;
+    return sizeof(float) * (size_t)B + sizeof(int) * (4 + (size_t)B) + 64;
+}
 
 int mhd_abi_version(void) { return MHD_ABI_VERSION; }
 
@@ -651,7 +822,7 @@ int mhd_set_search(int32_t algorithm)
 
 int mhd_set_candidates(int32_t n)
 {
-    if (n != 1 && n != 2) return fail(MHD_EINVAL, "candidates must be 1 or 2");
+    if (n != 1 && n != 2 && n != 4) return fail(MHD_EINVAL, "candidates must be 1, 2 or 4");
     g_candidates = n;
     return MHD_OK;
 }
@@ -666,7 +837,7 @@ int mhd_secular_batch(const mhd_problem_t* prob, const double* params, int32_t B
     if (!params || !chain || !period || !c || !delta) return fail(MHD_EINVAL, "NULL argument");
     if (B < 0 || N < 0) return fail(MHD_EINVAL, "negative size");
     if (N == 0) return MHD_OK;
-    hipLaunchKernelGGL(secular_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, *prob, params, B,
+    hipLaunchKernelGGL(secular_kernel, dim3(N), dim3(64), WAVE_LDS_BYTES, (hipStream_t)stream, *prob, params, B,
                        chain, period, c, N, delta);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_secular_batch launch");
@@ -679,7 +850,7 @@ int mhd_forward_batch(const mhd_problem_t* prob, const double* params, int32_t B
     if (!params || !vel || !status) return fail(MHD_EINVAL, "NULL argument");
     if (B < 0) return fail(MHD_EINVAL, "negative batch");
     if (B == 0) return MHD_OK;
-    hipLaunchKernelGGL(forward_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *prob, params, B,
+    hipLaunchKernelGGL(forward_kernel, dim3(B), dim3(64), WAVE_LDS_BYTES, (hipStream_t)stream, *prob, params, B,
                        vel, status, (unsigned long long*)n_evals, g_search);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_forward_batch launch");
@@ -721,13 +892,39 @@ int mhd_mh_steps(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t 
     if (B < 0 || n_steps < 0 || hist_every < 0) return fail(MHD_EINVAL, "negative size");
     if (!(T > 0.0)) return fail(MHD_EINVAL, "T must be positive");
     if (B == 0 || n_steps == 0) return MHD_OK;
-    if (g_candidates == 2 && !sample_prior) {
-        hipLaunchKernelGGL(mh_steps_pair_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, *prob,
-                           *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, accepted, status,
-                           hist_every, hist_m, hist_logL, hist_pred, (unsigned long long*)n_evals,
-                           g_search);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* ne = (unsigned long long*)n_evals;
+    if (g_candidates == 2 && !sample_prior && chains->sched && B >= 64 &&
+        B <= SCHED_MAX_CHAINS) {
+        // the most expensive chains with four candidates (first, so that they are resident when
+        // the others fill the GPU), the others beside them on a second stream
+        SideStream* side = side_stream();
+        if (!side) return MHD_EHIP;
+        hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, chains->sched, B);
+        hipError_t e = hipEventRecord(side->fork, s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
+        if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps fork");
+        hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(sched_cap4(B)), dim3(256),
+                           4 * WAVE_LDS_BYTES, s, *prob, *chains, B, n_steps, idx, cauchy, u_acc,
+                           T, rotate, accepted, status, hist_every, hist_m, hist_logL, hist_pred,
+                           ne, g_search, 1);
+        hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES,
+                           side->stream, *prob, *chains, B, n_steps, idx, cauchy, u_acc, T,
+                           rotate, accepted, status, hist_every, hist_m, hist_logL, hist_pred, ne,
+                           g_search, 1);
+        e = hipEventRecord(side->join, side->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, side->join, 0);
+        if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps join");
+    } else if (g_candidates == 2 && !sample_prior) {
+        hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES, s,
+                           *prob, *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, accepted,
+                           status, hist_every, hist_m, hist_logL, hist_pred, ne, g_search, 0);
+    } else if (g_candidates == 4 && !sample_prior) {
+        hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(B), dim3(256), 4 * WAVE_LDS_BYTES, s,
+                           *prob, *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, accepted,
+                           status, hist_every, hist_m, hist_logL, hist_pred, ne, g_search, 0);
     } else {
-        hipLaunchKernelGGL(mh_steps_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *prob,
+        hipLaunchKernelGGL(mh_steps_kernel, dim3(B), dim3(64), WAVE_LDS_BYTES, (hipStream_t)stream, *prob,
                            *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior,
                            accepted, status, hist_every, hist_m, hist_logL, hist_pred,
                            (unsigned long long*)n_evals, g_search);

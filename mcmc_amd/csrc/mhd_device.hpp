@@ -42,21 +42,20 @@ struct LayerTable {
     int L;
 };
 
-// The layer table of the chain this workgroup works on.  File scope so that the one
-// out-of-line secular-function body reads it with LDS instructions, not through a pointer.
-// One instance per wave of the workgroup (the Metropolis-Hastings kernel runs two waves, each
-// with its own candidate model); g_T is the instance of the calling wave.
-#ifndef MHD_NWAVE
-#define MHD_NWAVE 2
-#endif
-constexpr int NWAVE = MHD_NWAVE;
-
 // Out-of-line routines share one register budget: VGPRs + AGPRs <= 256, so that two waves fit
 // on a SIMD (512 registers per lane) and hide each other's FP64 latency.
 #define MHD_REGS __attribute__((amdgpu_waves_per_eu(2, 2)))
 #define MHD_NOINLINE __attribute__((noinline))
-__shared__ LayerTable g_Tw[NWAVE];
-#define g_T (g_Tw[threadIdx.x >> 6])
+
+// Scratch of one wave in dynamic LDS: the layer table of the model it works on, then the state
+// of the predicted search (mhd_search2.hpp).  A kernel that calls the forward model is launched
+// with WAVE_LDS_BYTES of dynamic LDS per wave of its workgroups; the out-of-line routines reach
+// the instance of the calling wave through g_T / g_PS, with LDS instructions and no pointer
+// argument.
+constexpr int WAVE_LDS_BYTES = 9 * 1024;
+constexpr int WAVE_LDS_SEARCH_OFFSET = (sizeof(LayerTable) + 15) / 16 * 16;
+extern __shared__ __align__(16) unsigned char mhd_wave_lds[];
+#define g_T (*reinterpret_cast<LayerTable*>(mhd_wave_lds + (threadIdx.x >> 6) * WAVE_LDS_BYTES))
 
 // Orders the LDS accesses of ONE wave (its lanes run in lock step, LDS operations of a wave
 // complete in order): a compiler fence, no hardware barrier.  Waves of a workgroup that work

@@ -42,8 +42,11 @@ struct PredictScratch {
     int trouble;  // repairs the last predicted curve needed (9: the predictor gave up)
 };
 
-__shared__ PredictScratch g_PSw[NWAVE];
-#define g_PS (g_PSw[threadIdx.x >> 6])
+static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
+              "WAVE_LDS_BYTES is too small");
+#define g_PS                                                                              \
+    (*reinterpret_cast<PredictScratch*>(mhd_wave_lds + (threadIdx.x >> 6) * WAVE_LDS_BYTES + \
+                                        WAVE_LDS_SEARCH_OFFSET))
 
 #pragma clang fp contract(off)
 

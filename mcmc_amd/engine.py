@@ -139,6 +139,7 @@ class DeviceChains:
         self.beta = None if beta is None else torch.tensor(
             np.asarray(beta, dtype=np.float64), **f64)
         self.n_evals = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.sched = torch.zeros(int(L.lib().mhd_sched_bytes(B)), dtype=torch.uint8, device=dev)
 
     def struct(self):
         return L.Chains(
@@ -147,7 +148,8 @@ class DeviceChains:
             rot=self.rot.data_ptr(), cov_sum=self.cov_sum.data_ptr(),
             n_cov=self.n_cov.data_ptr(), counters=self.counters.data_ptr(),
             counters_ind=None if self.counters_ind is None else self.counters_ind.data_ptr(),
-            beta=None if self.beta is None else self.beta.data_ptr())
+            beta=None if self.beta is None else self.beta.data_ptr(),
+            sched=None if self.sched is None else self.sched.data_ptr())
 
     def init_likelihood(self):
         """pred, logL of the current parameters; returns status [B]."""

@@ -9,9 +9,9 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[2, 1], ids=["pair", "single"])
+@pytest.fixture(autouse=True, params=[4, 2, 1], ids=["four", "two", "one"])
 def candidates(request):
-    """Every test runs with two candidates per chain in flight (the default) and with one."""
+    """Every test runs with four, two (the default) and one candidate per chain in flight."""
     from mcmc_amd import _lib as L
     L.check(L.lib().mhd_set_candidates(request.param))
     yield request.param
@@ -111,6 +111,56 @@ def test_batched_steps_vs_oracle(oracle, n_layers, P, B, S):
     np.testing.assert_array_equal(ch.counters.cpu().numpy(), ost.counters)
     assert int(ch.n_evals[0]) == lit
     assert (stat == 1).any()   # bounds rejections were exercised
+
+
+def test_scheduled_launches_do_not_change_the_chains(oracle, candidates):
+    """With the scratch of mhd_chains_t.sched the library measures what each chain costs and, from
+    the second call on, runs the expensive chains with four candidates in flight and the cheap
+    ones with one.  States, counters and the literal evaluation count must be those of the same
+    calls without it."""
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    if candidates != 2:
+        pytest.skip("scheduling applies to the default number of candidates")
+    rng = np.random.default_rng(5)
+    nl, P, B, S = 6, 24, 192, 90
+    NP = 2 * nl + 1
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
+    prob0 = DeviceProblem(nl, 1.75, periods)
+    starts = np.empty((0, NP))
+    while starts.shape[0] < B:
+        cand = np.array([oracle.sort_layers(x, nl)
+                         for x in rng.uniform(bounds[:, 0], bounds[:, 1], size=(2 * B, NP))])
+        _, st = prob0.forward(torch.tensor(cand, device=prob0.device))
+        starts = np.concatenate([starts, cand[st.cpu().numpy() == 0]])
+    starts = starts[:B]
+    obs = oracle.forward(starts[0], nl, 1.75, periods)[1] + 0.025 * rng.standard_normal(P)
+    prob = DeviceProblem(nl, 1.75, periods, obs, "normal", {"std": 0.025}, bounds)
+    dev = prob.device
+    idx = torch.tensor(rng.integers(0, NP, (S, B)).astype(np.int32), device=dev)
+    cauchy = torch.tensor(np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5)), device=dev)
+    u_acc = torch.tensor(rng.uniform(size=(S, B)), device=dev)
+    results, n4_seen = [], 0
+    for scheduled in (True, False):
+        ch = DeviceChains(prob, starts, 0.05)
+        if not scheduled:
+            ch.sched = None
+        assert int((ch.init_likelihood() != 0).sum()) == 0
+        acc = []
+        for a in range(0, S, 30):
+            out = ch.steps(idx[a:a + 30], cauchy[a:a + 30], u_acc[a:a + 30], hist_every=10)
+            acc.append(torch.cat([out["accepted"].flatten().to(torch.float64),
+                                  out["hist_logL"].flatten()]))
+            if scheduled:
+                n4_seen = max(n4_seen, int(ch.sched[4 * B:4 * B + 4].view(torch.int32)[0]))
+        results.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(),
+                        torch.cat(acc), int(ch.n_evals[0])))
+    a, b = results
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+    assert a[5] == b[5]
+    assert n4_seen > 0   # the schedule really gave some chains four candidates
 
 
 def test_batched_rotated_steps_vs_oracle(oracle):

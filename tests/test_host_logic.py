@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.mhd_abi_version() == L.ABI_VERSION
     # struct layouts agree with the header's field order and sizes
     assert ctypes.sizeof(L.Problem) == 8 * 4 + 3 * 8 + 5 * 8
-    assert ctypes.sizeof(L.Chains) == 11 * 8
+    assert ctypes.sizeof(L.Chains) == 12 * 8
 
 
 def test_argument_validation_without_gpu():
