@@ -82,7 +82,7 @@ def cpu_baseline(periods, bounds, obs, starts, seed, budget_s=12.0):
             oracle.mh_step(S, idx, cz, ua, nl, VPVS, periods, obs, "normal", noise)
             n_steps += 1
             dt = time.perf_counter() - t0
-            if dt > budget_s / 2 or n_steps >= 400:
+            if dt > budget_s / 2 or n_steps >= 2000:
                 break
         res[label] = (B * n_steps / dt, nt, B, n_steps)
         oracle.set_threads(1)
@@ -212,7 +212,8 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": None,
-                "kernel": "mh_steps_pair_kernel" if args.candidates == 2 else "mh_steps_kernel",
+                "kernel": "mh_steps_multi_kernel<2> (with mh_steps_multi_kernel<4> beside it)"
+                if args.candidates == 2 else "mh_steps_multi_kernel<%d>" % args.candidates,
                 "launch_ms": launch_s * 1e3,
                 "algorithmic_evals_per_launch": lit / n_launch,
                 "executed_evals_per_launch": ex / n_launch,
