@@ -5,8 +5,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mhd_api.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "mhd_device.hpp"), os.path.join(HERE, "csrc", "mhd_math.hpp"),
-        os.path.join(os.path.dirname(HERE), "include", "mcmc_amd.h")]
+DEPS = [SRC] + [os.path.join(HERE, "csrc", h)
+                for h in ("mhd_device.hpp", "mhd_search2.hpp", "mhd_math.hpp")] + \
+       [os.path.join(os.path.dirname(HERE), "include", "mcmc_amd.h")]
 OUT = os.path.join(HERE, "lib", "libmcmc_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
