@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
             build_layer_table(T, test, nl, p.vpvs, lane);
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred,
-                                       scratch, cnt, policy.stepwise());
+                                       scratch, cnt, policy.stepwise(), pred);
                 if (search == 2)
                     policy.update(1, __builtin_amdgcn_readfirstlane(g_PS.trouble) >= 2);
             } else {
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             build_layer_table(T, test[w], nl, p.vpvs, lane);
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
-                                       scratch[w], cnt, policy.stepwise());
+                                       scratch[w], cnt, policy.stepwise(), pred);
                 trouble = __builtin_amdgcn_readfirstlane(g_PS.trouble);
             } else {
                 st = forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],

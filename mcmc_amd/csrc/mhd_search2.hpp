@@ -34,6 +34,8 @@ struct PredictScratch {
     signed char slo[MAXP], shi[MAXP];
     double fm[64];  // lane values of the current stage-1 round
     int fe[64];
+    double wbase[8];  // windows of the current stage-1 round: first abscissa ...
+    int woff[9];      // ... and first lane
     // what the replay did for each period (see replay_period)
     double rstart[MAXP];
     unsigned long long rbits[MAXP];
@@ -72,10 +74,13 @@ __device__ __forceinline__ int mask_sign(unsigned long long neg, unsigned long l
 // function of period 0 at the floor).
 // n < P: period n-1 has no sign change below the ceiling (its bracket is "constant sign"),
 // the sequential search fails there.  -1: give up (the caller uses the sequential search).
-__device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg,
-                                                        int P, double tscale, double dc,
-                                                        double rprev_in, int sigma0_in,
-                                                        EvalCount& cnt)
+// hint: a curve of a similar model (the chain's current one), or nullptr.  Its shape -- the
+// differences between its periods -- places small windows around the expected roots, eight
+// periods per round; where that fails, and without a hint, the windows start at the expected
+// start of the sequential scan and are 8, 16, 32 or 64 abscissae wide.
+__device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, int P,
+                                           double tscale, double dc, double rprev_in,
+                                           int sigma0_in, const double* hint, EvalCount& cnt)
 {
     PredictScratch& S = g_PS;
     const int lane = threadIdx.x & 63;
@@ -83,36 +88,75 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg,
     int k0 = kbeg, sigma0 = sigma0_in, carry_sign = 0, rounds = 0;
     double rprev = rprev_in, inc = 1.0, carry_base = 0.0;
     bool have_inc = false, carry = false;
+    bool hint_ok = true;  // the next round may use the hint's shape
+    int hint_misses = 0;  // rounds in which it bracketed nothing
+#ifdef MHD_PROFILE
+    int prof_first = 0, prof_shaped = 0;
+#endif
 
     while (k0 < P) {
         if (++rounds > 96) return -1;
-        int lg = 0;  // log2 of the number of periods in this round
-        if (!(k0 == 0 || carry)) {
-            const double ai = fabs(inc);
-            lg = !have_inc ? 2 : (ai <= 2.0 ? 3 : (ai <= 5.0 ? 2 : (ai <= 12.0 ? 1 : 0)));
+        // ---- the windows of this round: period k0+q gets the lanes woff[q]..woff[q+1]-1 and
+        // the abscissae wbase[q] + j*dc
+        int nq = 0, g = 1;
+        const bool shaped = hint && hint_ok && k0 > 0 && !carry;
+#ifdef MHD_PROFILE
+        prof_first += (k0 == 0);
+        prof_shaped += shaped;
+#endif
+        if (shaped) {
+            // around the expected root of each period, wider with the distance from the last
+            // known root: 5, 5, 7, 7, 9, 9, 11, 11 abscissae
+            int off = 0;
+            for (int q = 0; q < 8 && k0 + q < P; ++q) {
+                const double rq = rprev + (hint[k0 + q] - hint[k0 - 1]);
+                const int m = 2 + q / 2;
+                if (lane == 0) {
+                    S.woff[q] = off;
+                    S.wbase[q] = rq - (m + 0.5) * dc;
+                }
+                off += 2 * m + 1;
+                nq = q + 1;
+            }
+            if (lane == 0) S.woff[nq] = off;
+        } else {
+            int lg = 0;  // log2 of the number of periods in this round
+            if (!(k0 == 0 || carry)) {
+                const double ai = fabs(inc);
+                lg = !have_inc ? 2 : (ai <= 2.0 ? 3 : (ai <= 5.0 ? 2 : (ai <= 12.0 ? 1 : 0)));
+            }
+            g = 1 << lg;
+            const int W = 64 >> lg;
+            nq = (P - k0 < g) ? P - k0 : g;
+            const double pinc = have_inc ? inc : 1.0;
+            if (lane == 0) {
+                for (int q = 0; q < nq; ++q) {
+                    double b;
+                    if (carry && q == 0) {
+                        b = carry_base;
+                    } else if (k0 + q == 0) {
+                        b = cc;
+                    } else {
+                        int mlo = (q == 0) ? 0 : (1 + (q + 1) / 2);
+                        if (W >= 16) mlo *= 2;
+                        b = rprev + q * pinc * dc - 1.5 * dc - mlo * dc;
+                        if (b < cc - 2.0 * dc) b = cc - 2.0 * dc;
+                    }
+                    S.woff[q] = q * W;
+                    S.wbase[q] = b;
+                }
+                S.woff[nq] = nq * W;
+            }
         }
-        const int g = 1 << lg, W = 64 >> lg;
-        const int gact = (P - k0 < g) ? P - k0 : g;
-        // window bases are fixed before the round's evaluations (frozen copies)
-        const double pinc0 = have_inc ? inc : 1.0, rprev0 = rprev, cbase0 = carry_base;
-        const bool carry0 = carry;
-        const int kfirst = k0;
-        auto base_of = [&](int q) -> double {
-            if (carry0 && q == 0) return cbase0;
-            if (kfirst + q == 0) return cc;
-            const double pstart = rprev0 + q * pinc0 * dc - 1.5 * dc;
-            int mlo = (q == 0) ? 0 : (1 + (q + 1) / 2);
-            if (W >= 16) mlo *= 2;
-            double b = pstart - mlo * dc;
-            if (b < cc - 2.0 * dc) b = cc - 2.0 * dc;
-            return b;
-        };
-        const int jj = lane >> (6 - lg), j = lane & (W - 1);
-        const bool active = jj < gact;
+        wave_sync();
+        int jj = 0;
+        for (int q = 1; q < nq; ++q) jj += (lane >= S.woff[q]);
+        const int nlanes = S.woff[nq];
+        const bool active = lane < nlanes;
         SecVal v = {0.0, 0};
         if (active) {
             const double omega = TWOPI / (t[k0 + jj] / tscale);
-            v = eval_secular(wave, omega, base_of(jj) + j * dc);
+            v = eval_secular(wave, omega, S.wbase[jj] + (lane - S.woff[jj]) * dc);
         }
         const unsigned long long neg = __ballot(active && v.m < 0.0);
         const unsigned long long pos = __ballot(active && v.m > 0.0);
@@ -120,14 +164,39 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg,
         S.fm[lane] = v.m;
         S.fe[lane] = v.e;
         wave_sync();
-        cnt.exec += (unsigned long long)(gact * W);
+        cnt.exec += (unsigned long long)nlanes;
         if (k0 == 0 && !carry) sigma0 = mask_sign(neg, pos, 0);
 
         int resolved = 0;
         bool carried_now = false;
-        for (int q = 0; q < gact; ++q) {
-            const int k = k0 + q, bit0 = q * W;
-            const double s = base_of(q);
+        if (shaped) {
+            // a period is bracketed when its window holds exactly one sign change (whether the
+            // sequential scan meets another one before it is for the verification to find out)
+            for (int q = 0; q < nq; ++q) {
+                const int k = k0 + q, bit0 = S.woff[q], W = S.woff[q + 1] - bit0;
+                const unsigned long long wm = (1ull << W) - 1ull;
+                const unsigned long long ng = (neg >> bit0) & wm, ps = (pos >> bit0) & wm;
+                const unsigned long long chg = ((ng << 1) & ps) | ((ps << 1) & ng);
+                if (__popcll(chg) != 1 || __popcll(ng | ps) != W) break;
+                const int j = (int)__ffsll((long long)chg) - 1;  // sign change between j-1 and j
+                const double sb = S.wbase[q];
+                S.lo[k] = sb + (j - 1) * dc;
+                S.fam[k] = (float)S.fm[bit0 + j - 1];
+                S.fae[k] = (short)S.fe[bit0 + j - 1];
+                S.hi[k] = sb + j * dc;
+                S.fbm[k] = (float)S.fm[bit0 + j];
+                S.fbe[k] = (short)S.fe[bit0 + j];
+                const double nr = sb + (j - 0.5) * dc;
+                inc = (nr - rprev) / dc;
+                have_inc = true;
+                rprev = nr;
+                ++resolved;
+            }
+            nq = 0;  // skips the lattice pass below
+        }
+        for (int q = 0; q < nq; ++q) {
+            const int k = k0 + q, bit0 = S.woff[q], W = S.woff[q + 1] - bit0;
+            const double s = S.wbase[q];
             int start, s1;
             if (carry && q == 0) {
                 start = -1;
@@ -245,12 +314,27 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg,
             carry = false;
         }
         k0 += resolved;
+        if (resolved > 0 && !shaped && hint_misses < 4) hint_ok = true;
         if (resolved == 0 && !carried_now) {
-            if (g == 1) return -1;
-            inc = (fabs(inc) + 1.0) * 4.0;  // widen the windows
+            if (shaped) {
+                hint_ok = false;  // this period from its scan start
+                ++hint_misses;
+            } else {
+                if (g == 1) return -1;
+                inc = (fabs(inc) + 1.0) * 4.0;  // widen the windows
+            }
         }
     }
     wave_sync();
+#ifdef MHD_PROFILE
+    if (lane == 0) {
+        atomicAdd(&g_prof[14], (unsigned long long)rounds);
+        atomicAdd(&g_prof[15], 1ull);
+        atomicAdd(&g_prof[13], (unsigned long long)(hint && hint_ok));
+        atomicAdd(&g_prof[11], (unsigned long long)prof_first);
+        atomicAdd(&g_prof[12], (unsigned long long)prof_shaped);
+    }
+#endif
     return P;
 }
 
@@ -483,9 +567,10 @@ __device__ __forceinline__ double replay_abscissa(int k, int q, double dc)
 // Fundamental-mode phase velocities c[0..P-1] (LDS) of the table in g_T, bit-identical to
 // phase_curve_wave(..., mode = 0, ...).  Returns MHD_ST_OK or MHD_ST_NOROOT.
 // stepwise > 0: predict with predict_stepwise(levels = stepwise) instead of predict_coarse.
+// hint: see predict_coarse.
 __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int P, double tscale,
                                                   double dc, double* c, EvalCount& cnt,
-                                                  int stepwise)
+                                                  int stepwise, const double* hint)
 {
     const LayerTable& T = g_T;
     PredictScratch& S = g_PS;
@@ -494,7 +579,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
     dc = fabs(dc);
     PROF_T0
     int nP = stepwise ? predict_stepwise(wave, t, 0, P, tscale, dc, 0.0, 0, stepwise, cnt)
-                      : predict_coarse(wave, t, 0, P, tscale, dc, 0.0, 0, cnt);
+                      : predict_coarse(wave, t, 0, P, tscale, dc, 0.0, 0, hint, cnt);
     PROF_ADD(0)
     S.trouble = (nP < 0) ? 9 : 0;
     if (nP < 0) {
@@ -617,7 +702,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             // the sequential search moved to another branch than the predictor's: predict the
             // remaining periods again, continuing from the root it found
             nP = stepwise ? predict_stepwise(wave, t, kstart, P, tscale, dc, cr, s1st, stepwise, cnt)
-                          : predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, cnt);
+                          : predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, hint, cnt);
             PROF_ADD(0)
             if (nP < 0) {
                 const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
@@ -663,16 +748,16 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
 __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode, int itype,
                                         const double* t, int P, double dc, double dt,
                                         double* vel, double* scratch, EvalCount& cnt,
-                                        int stepwise = 0)
+                                        int stepwise = 0, const double* hint = nullptr)
 {
     if (mode != 0)
         return forward_wave(T, wave, mode, itype, t, P, dc, dt, vel, scratch, cnt);
-    if (itype == MHD_PHASE) return phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt, stepwise);
+    if (itype == MHD_PHASE) return phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt, stepwise, hint);
     double* c1 = scratch;
     double* c2 = scratch + P;
-    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt, stepwise);
+    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt, stepwise, nullptr);
     if (st != MHD_ST_OK) return st;
-    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt, stepwise);
+    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt, stepwise, nullptr);
     if (st != MHD_ST_OK) return st;
     for (int k = 0; k < P; ++k) {
         if (c1[k] > 0.0 && c2[k] > 0.0) {
