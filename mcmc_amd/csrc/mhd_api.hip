@@ -461,7 +461,7 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B)
             const float with4 = key[0] / SCHED_CONSUMED[4];
             const int cap = sched_cap4(B);
             while (n4 < cap && key[n4] / SCHED_CONSUMED[2] > with4) {
-                const int ns = n4 + 1 + SCHED_SPARE;
+                const int ns = n4 + 1 + SCHED_SPARE + (n4 + 1) / 2;
                 if (n4 + 1 + 2 * ns >= B) break;
                 const float target = fmaxf(with4, key[n4 + 1] / SCHED_CONSUMED[2]);
                 if (key[B - 2 * ns] > target) break;
@@ -570,6 +570,12 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
 #ifdef MHD_PROFILE
     const long long k_w0 = wall_clock64();
     if (writer && lane == 0 && ib < 2048) g_times[2 * ib] = (unsigned long long)k_w0;
+    if (writer && lane == 0 && ib < 1024) {
+        // where this workgroup runs: HW_ID (register 4) and XCC_ID (register 20)
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+        g_blk[ib * 8 + 5] = ((unsigned long long)xcc << 32) | hw | ((unsigned long long)NW << 60) | ((unsigned long long)split << 59);
+    }
 #endif
     group_sync();
 
@@ -636,6 +642,9 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     while (s < S) {
         // ---- this wave's candidate: the (w-w0+1)-th proposal from step s on that passes the
         // bounds
+#ifdef MHD_PROFILE
+        const long long _r0 = clock64();
+#endif
         int jc = S, found = 0;
         for (int j = s; j < S; ++j) {
             const int kk = idx[(size_t)j * B + ib];
@@ -670,7 +679,16 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             r_logL[w] = lnew;
             r_lit[w] = cnt.lit;
         }
+#ifdef MHD_PROFILE
+        const long long _b0 = clock64();
+#endif
         group_sync();
+#ifdef MHD_PROFILE
+        if (lane == 0) {
+            atomicAdd(&g_prof[9], (unsigned long long)(clock64() - _b0));   // wait for the partner
+            atomicAdd(&g_prof[10], (unsigned long long)(_b0 - _r0));        // scan + forward
+        }
+#endif
 
         // ---- settle the steps in order (all waves of the chain follow; the first one writes)
         int ran = 0;

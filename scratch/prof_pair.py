@@ -26,6 +26,7 @@ raw=np.array(list(bb),dtype=np.uint64).reshape(1024,8)
 b=np.zeros((1024,8)); b[:,0]=(raw[:,7]>>np.uint64(40)); b[:,1]=((raw[:,7]>>np.uint64(20))&np.uint64(0xFFFFF)); b[:,2]=(raw[:,7]&np.uint64(0xFFFFF)); cyc=raw[:,:7].astype(np.float64)
 nst=750.0
 out=(ctypes.c_ulonglong*16)(); lib.mhd_debug_profile(out,0); o=list(out); print("coarse: calls %d rounds/call %.2f hint kept %.2f | rounds on period 0: %.2f shaped rounds %.2f"%(o[15], o[14]/max(o[15],1), o[13]/max(o[15],1), o[11]/max(o[15],1), o[12]/max(o[15],1)))
+print("round: scan+forward cycles %.3g, barrier wait cycles %.3g (%.3f of the sum)"%(o[10],o[9],o[9]/(o[9]+o[10])))
 print("per chain over 750 steps: rounds/step mean %.3f, forwards/step %.3f, sequential-search share %.3f"%(b[:,0].mean()/nst, b[:,1].mean()/nst, b[:,2].sum()/b[:,1].sum()))
 order=np.argsort(dur)
 for label,idxs in (("fastest 3",order[:3]),("median 3",order[510:513]),("slowest 10",order[-10:])):

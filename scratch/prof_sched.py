@@ -6,6 +6,12 @@ L.LIB_PATH=os.path.join(ROOT,'mcmc_amd','lib','libmcmc_amd_prof.so')
 lib=L.lib()
 sys.argv=['bench.py','--steps','500','--warmup','250','--no-cpu']+sys.argv[1:]
 import runpy, io, contextlib
+import mcmc_amd.engine as E
+_orig=E.DeviceChains.__init__
+_keep=[]
+def _init(self,*a,**k):
+    _orig(self,*a,**k); _keep.append(self)
+E.DeviceChains.__init__=_init
 import numpy as np
 buf=io.StringIO()
 with contextlib.redirect_stdout(buf):
@@ -23,3 +29,36 @@ late=np.argsort(st)[-12:]
 print("latest starters:", [(int(i), int(st[i]), int(en[i])) for i in late])
 slow=np.argsort(en)[-8:]
 print("latest finishers:", [(int(i), int(st[i]), int(en[i])) for i in slow])
+
+ch=_keep[-1]; B=1024
+raw=ch.sched.cpu().numpy()
+cost=raw[:4*B].view(np.float32).astype(np.float64); n4=int(raw[4*B:4*B+4].view(np.int32)[0]); ns=int(raw[4*B+4:4*B+8].view(np.int32)[0]); order=raw[4*B+16:4*B+16+4*B].view(np.int32)
+print("n4",n4,"nsplit",ns,"chains starting later than 1 ms:",int((st>1000).sum()))
+# cost is ticks per step at one candidate; predicted us/step per class
+cons={1:1.0,2:1.65,4:2.35}
+cls=np.full(B,2); cls[order[:n4]]=4; cls[order[B-2*ns:]]=1
+pred_us=cost/np.array([cons[c] for c in cls])/100.0
+act_us=dur/250
+for c in (4,2,1):
+    m=cls==c
+    print("class J=%d: n=%d predicted us/step p50 %.0f max %.0f | actual p50 %.0f max %.0f | ratio actual/pred p10 %.2f p50 %.2f p90 %.2f"%(c,m.sum(),np.median(pred_us[m]),pred_us[m].max(),np.median(act_us[m]),act_us[m].max(),*np.percentile(act_us[m]/pred_us[m],[10,50,90])))
+print("sum of per-chain busy wave-time / (2048 waves x makespan): %.3f"%(((dur*np.array([ {4:4,2:2,1:1}[c] for c in cls])).sum())/(2048*en.max())))
+
+bb=(ctypes.c_ulonglong*8192)()
+lib.mhd_debug_blk(bb,0)
+raw5=np.array(list(bb),dtype=np.uint64).reshape(1024,8)[:,5]
+hw=(raw5&np.uint64(0xFFFFFFFF)).astype(np.int64); xcc=((raw5>>np.uint64(32))&np.uint64(0xF)).astype(np.int64)
+nwv=(raw5>>np.uint64(60)).astype(np.int64); sp=((raw5>>np.uint64(59))&np.uint64(1)).astype(np.int64)
+cu=(hw>>8)&0xF; sh=(hw>>12)&1; se=(hw>>13)&7
+key=xcc*1000+se*100+sh*16+cu
+early=st<1000
+waves=np.where(sp==1,1,nwv)
+import collections
+occ=collections.Counter(); quads=collections.Counter()
+for i in range(1024):
+    if early[i]:
+        occ[key[i]]+=waves[i]
+        if nwv[i]==4: quads[key[i]]+=1
+print("distinct CUs seen:",len(occ),"waves resident at start: total",sum(occ.values()),"histogram of waves per CU:",sorted(collections.Counter(occ.values()).items()))
+print("CUs with a quad: waves per CU histogram:",sorted(collections.Counter(occ[k] for k in quads).items()), "quads per CU:",sorted(collections.Counter(quads.values()).items()))
+print("xcc distribution of early waves:",sorted(collections.Counter({x:sum(v for k,v in occ.items() if k//1000==x) for x in range(8)}).items()))
