@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) MHD_REGS void forward_kernel(mhd_problem_t p, c
     EvalCount cnt = {0, 0};
     const int st = (search == 2)
                        ? forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, out,
-                                           scratch, cnt)
+                                           scratch, cnt, 0, t, false)
                        : forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, out, scratch,
                                       cnt);
     __syncthreads();
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
             build_layer_table(T, test, nl, p.vpvs, lane);
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred,
-                                       scratch, cnt, policy.stepwise(), pred);
+                                       scratch, cnt, policy.stepwise(), pred, p.itype == MHD_PHASE);
                 if (search == 2)
                     policy.update(1, __builtin_amdgcn_readfirstlane(g_PS.trouble) >= 2);
             } else {
@@ -400,6 +400,7 @@ struct SchedView {
     float* cost;  // [B]
     int* n4;      // [0] n4, [1] number of split workgroups (+ padding)
     int* order;   // [B]
+    unsigned char* level;  // [B] SearchPolicy level each chain ended its last launch with
 };
 
 __host__ __device__ inline int sched_cap4(int B) { return B / 16 > 0 ? B / 16 : 1; }
@@ -410,6 +411,7 @@ __host__ __device__ inline SchedView sched_view(void* buf, int B)
     v.cost = (float*)buf;
     v.n4 = (int*)(v.cost + B);
     v.order = v.n4 + 4;
+    v.level = (unsigned char*)(v.order + B);
     return v;
 }
 
@@ -565,8 +567,17 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     const ProposalFrame frame = {lo, hi, rg, wid, R, nl, NP};
     long long c_acc = 0, c_rej = 0, c_bnd = 0, c_fm = 0;
     unsigned long long lit = 0, exec = 0;
-    // how the curves of this chain are searched (see SearchPolicy)
+    // how the curves of this chain are searched (see SearchPolicy); a chain goes on at the
+    // level its last launch ended with
+    const bool keeps = ch.sched && B <= SCHED_MAX_CHAINS;
     SearchPolicy policy = {search == 2 ? 0 : 3, 0};
+    if (search == 2 && keeps) {
+        // (NW = 4 serves the expensive chains, which mostly sit at level 1 or above; reading
+        // the level there trips an instruction-selection bug of the compiler, so it is fixed)
+        const int lv = (NW == 4) ? 1 : ((int)sched_view(ch.sched, B).level[ib] & 3);
+        policy.level = lv;
+        policy.left = lv > 0 ? 8 : 0;
+    }
 #ifdef MHD_PROFILE
     const long long k_w0 = wall_clock64();
     if (writer && lane == 0 && ib < 2048) g_times[2 * ib] = (unsigned long long)k_w0;
@@ -662,7 +673,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             build_layer_table(T, test[w], nl, p.vpvs, lane);
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
-                                       scratch[w], cnt, policy.stepwise(), pred);
+                                       scratch[w], cnt, policy.stepwise(), pred, p.itype == MHD_PHASE);
                 trouble = __builtin_amdgcn_readfirstlane(g_PS.trouble);
             } else {
                 st = forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
@@ -724,7 +735,8 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
 #ifdef MHD_PROFILE
     if (writer && lane == 0 && ib < 2048) g_times[2 * ib + 1] = (unsigned long long)wall_clock64();
 #endif
-    if (writer && lane == 0 && ch.sched && B <= SCHED_MAX_CHAINS) {
+    if (writer && lane == 0 && keeps) {
+        if (search == 2) sched_view(ch.sched, B).level[ib] = (unsigned char)policy.level;
         float* cost = sched_view(ch.sched, B).cost;
         const float now = (float)(wall_clock64() - t_begin) * SCHED_CONSUMED[nw] / (float)S;
         const float old = cost[ib];
@@ -794,7 +806,7 @@ extern "C" {
 size_t mhd_sched_bytes(int32_t B)
 {
     if (B < 0) B = 0;
-    return sizeof(float) * (size_t)B + sizeof(int) * (4 + (size_t)B) + 64;
+    return sizeof(float) * (size_t)B + sizeof(int) * (4 + (size_t)B) + (size_t)B + 64;
 }
 
 int mhd_abi_version(void) { return MHD_ABI_VERSION; }

@@ -74,13 +74,14 @@ __device__ __forceinline__ int mask_sign(unsigned long long neg, unsigned long l
 // function of period 0 at the floor).
 // n < P: period n-1 has no sign change below the ceiling (its bracket is "constant sign"),
 // the sequential search fails there.  -1: give up (the caller uses the sequential search).
-// hint: a curve of a similar model (the chain's current one), or nullptr.  Its shape -- the
+// hint (if use_hint): a curve of a similar model (the chain's current one).  Its shape -- the
 // differences between its periods -- places small windows around the expected roots, eight
 // periods per round; where that fails, and without a hint, the windows start at the expected
 // start of the sequential scan and are 8, 16, 32 or 64 abscissae wide.
 __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, int P,
                                            double tscale, double dc, double rprev_in,
-                                           int sigma0_in, const double* hint, EvalCount& cnt)
+                                           int sigma0_in, const double* hint, bool use_hint,
+                                           EvalCount& cnt)
 {
     PredictScratch& S = g_PS;
     const int lane = threadIdx.x & 63;
@@ -99,7 +100,7 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
         // ---- the windows of this round: period k0+q gets the lanes woff[q]..woff[q+1]-1 and
         // the abscissae wbase[q] + j*dc
         int nq = 0, g = 1;
-        const bool shaped = hint && hint_ok && k0 > 0 && !carry;
+        const bool shaped = use_hint && hint_ok && k0 > 0 && !carry;
 #ifdef MHD_PROFILE
         prof_first += (k0 == 0);
         prof_shaped += shaped;
@@ -330,7 +331,7 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
     if (lane == 0) {
         atomicAdd(&g_prof[14], (unsigned long long)rounds);
         atomicAdd(&g_prof[15], 1ull);
-        atomicAdd(&g_prof[13], (unsigned long long)(hint && hint_ok));
+        atomicAdd(&g_prof[13], (unsigned long long)(use_hint && hint_ok));
         atomicAdd(&g_prof[11], (unsigned long long)prof_first);
         atomicAdd(&g_prof[12], (unsigned long long)prof_shaped);
     }
@@ -570,7 +571,8 @@ __device__ __forceinline__ double replay_abscissa(int k, int q, double dc)
 // hint: see predict_coarse.
 __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int P, double tscale,
                                                   double dc, double* c, EvalCount& cnt,
-                                                  int stepwise, const double* hint)
+                                                  int stepwise, const double* hint,
+                                                  bool use_hint)
 {
     const LayerTable& T = g_T;
     PredictScratch& S = g_PS;
@@ -579,7 +581,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
     dc = fabs(dc);
     PROF_T0
     int nP = stepwise ? predict_stepwise(wave, t, 0, P, tscale, dc, 0.0, 0, stepwise, cnt)
-                      : predict_coarse(wave, t, 0, P, tscale, dc, 0.0, 0, hint, cnt);
+                      : predict_coarse(wave, t, 0, P, tscale, dc, 0.0, 0, hint, use_hint, cnt);
     PROF_ADD(0)
     S.trouble = (nP < 0) ? 9 : 0;
     if (nP < 0) {
@@ -702,7 +704,8 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             // the sequential search moved to another branch than the predictor's: predict the
             // remaining periods again, continuing from the root it found
             nP = stepwise ? predict_stepwise(wave, t, kstart, P, tscale, dc, cr, s1st, stepwise, cnt)
-                          : predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, hint, cnt);
+                          : predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, hint, use_hint,
+                                           cnt);
             PROF_ADD(0)
             if (nP < 0) {
                 const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
@@ -748,16 +751,18 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
 __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode, int itype,
                                         const double* t, int P, double dc, double dt,
                                         double* vel, double* scratch, EvalCount& cnt,
-                                        int stepwise = 0, const double* hint = nullptr)
+                                        int stepwise, const double* hint, bool use_hint)
 {
+    // (hint is never tested against null: a null test of a pointer into LDS trips the compiler;
+    // without a hint the callers pass any valid pointer and use_hint = false)
     if (mode != 0)
         return forward_wave(T, wave, mode, itype, t, P, dc, dt, vel, scratch, cnt);
-    if (itype == MHD_PHASE) return phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt, stepwise, hint);
+    if (itype == MHD_PHASE) return phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt, stepwise, hint, use_hint);
     double* c1 = scratch;
     double* c2 = scratch + P;
-    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt, stepwise, nullptr);
+    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt, stepwise, t, false);
     if (st != MHD_ST_OK) return st;
-    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt, stepwise, nullptr);
+    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt, stepwise, t, false);
     if (st != MHD_ST_OK) return st;
     for (int k = 0; k < P; ++k) {
         if (c1[k] > 0.0 && c2[k] > 0.0) {
