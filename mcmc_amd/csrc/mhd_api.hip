@@ -393,6 +393,14 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
 // chains at its tail run with one candidate, all others with two, so a launch keeps at most two
 // waves per chain on average and the expensive chains finish closer to the others.
 constexpr int SCHED_MAX_CHAINS = 4096;  // one workgroup sorts them in LDS
+// a chain gets four candidates when with two it is expected to take longer than this fraction of
+// the time of the most expensive chain with four (the estimates are some 10 % uncertain)
+#ifndef SCHED_MARGIN
+#define SCHED_MARGIN 0.85f
+#endif
+#ifndef SCHED_GAIN
+#define SCHED_GAIN 0.5f
+#endif
 constexpr int SCHED_SPARE = 8;           // workgroup places left free in a scheduled launch
 __device__ __constant__ float SCHED_CONSUMED[5] = {0.0f, 1.0f, 1.65f, 2.07f, 2.35f};
 
@@ -403,7 +411,7 @@ struct SchedView {
     unsigned char* level;  // [B] SearchPolicy level each chain ended its last launch with
 };
 
-__host__ __device__ inline int sched_cap4(int B) { return B / 16 > 0 ? B / 16 : 1; }
+__host__ __device__ inline int sched_cap4(int B) { return B / 8 > 0 ? B / 8 : 1; }
 
 __host__ __device__ inline SchedView sched_view(void* buf, int B)
 {
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B)
         if (!unknown) {
             const float with4 = key[0] / SCHED_CONSUMED[4];
             const int cap = sched_cap4(B);
-            while (n4 < cap && key[n4] / SCHED_CONSUMED[2] > with4) {
+            while (n4 < cap && key[n4] / SCHED_CONSUMED[2] > SCHED_MARGIN * with4) {
                 const int ns = n4 + 1 + SCHED_SPARE + (n4 + 1) / 2;
                 if (n4 + 1 + 2 * ns >= B) break;
                 const float target = fmaxf(with4, key[n4 + 1] / SCHED_CONSUMED[2]);
@@ -740,7 +748,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         float* cost = sched_view(ch.sched, B).cost;
         const float now = (float)(wall_clock64() - t_begin) * SCHED_CONSUMED[nw] / (float)S;
         const float old = cost[ib];
-        cost[ib] = old > 0.0f ? 0.5f * (old + now) : now;
+        cost[ib] = old > 0.0f ? old + SCHED_GAIN * (now - old) : now;
     }
     if (writer) {
         if (lane < NP) ch.m[(size_t)ib * NP + lane] = m[lane];
