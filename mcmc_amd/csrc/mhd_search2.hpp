@@ -492,39 +492,39 @@ __device__ __forceinline__ int replay_period(int k, double& c1io, double clow, d
     const int slo = __builtin_amdgcn_readfirstlane((int)S.slo[k]);
     const int shi = __builtin_amdgcn_readfirstlane((int)S.shi[k]);
     if (slo == 0 || shi == 0) return -1;
+    if (slo == shi) return -1;
+    // slo != shi: the inferred sign of an abscissa is known by its side of the bracket alone
+    // (below: x <= lo).  The side is uniform; kept as a scalar, it costs no vector compare of
+    // signs, and the side of c1 cannot change during the halvings.
     const double start = c1io;
     double c1 = start, c2;
-    int s1 = (c1 <= lo) ? slo : shi;
-    const int sfirst = s1;
-    const bool upward = ifirst || s1st * s1 >= 0;
+    bool below1 = uni(c1 <= lo);
+    const int sfirst = below1 ? slo : shi;
+    const bool upward = ifirst || s1st * sfirst >= 0;
     const double step = upward ? dc : -dc;
     int ns = 1;
     bool plain;
     for (;;) {
         c2 = c1 + step;
         ++ns;
-        const int s2 = (c2 <= lo) ? slo : shi;
-        plain = (c2 > clow) && (ns <= 62);
-        if (uni(s1 != s2 || !plain || c2 < cm || c2 >= top)) {
-            plain = plain && (s1 != s2);
+        const bool below2 = uni(c2 <= lo);
+        plain = uni(c2 > clow) && (ns <= 62);
+        if (below1 != below2 || !plain || uni(c2 < cm || c2 >= top)) {
+            plain = plain && (below1 != below2);
             break;
         }
         c1 = c2;
-        s1 = s2;
     }
-    if (!uni(plain)) return -1;
+    if (!plain) return -1;
     unsigned long long bits = 0;
     int nh = 0;
     double c3;
     for (;;) {
         c3 = 0.5 * (c1 + c2);
-        const int s3 = (c3 <= lo) ? slo : shi;
-        const bool left = s3 * s1 < 0;
-        bits |= left ? (1ull << nh) : 0ull;
+        const bool left = uni(c3 <= lo) != below1;  // the sign at c3 differs from the one at c1
+        bits |= (unsigned long long)left << nh;
         ++nh;
-        c2 = left ? c3 : c2;
-        c1 = left ? c1 : c3;
-        s1 = left ? s1 : s3;
+        if (left) c2 = c3; else c1 = c3;
         if (uni(fabs(c1 - c2) <= 1.0e-6 * c1)) break;
         if (nh >= 40) return -1;
     }
@@ -538,6 +538,7 @@ __device__ __forceinline__ int replay_period(int k, double& c1io, double clow, d
     count = ns + nh;
     if (ifirst) s1st = __builtin_amdgcn_readfirstlane(sfirst);
     c1io = c3;
+
     return uni(c3 <= betmx) ? 1 : 0;
 }
 
