@@ -220,7 +220,7 @@ def main():
                 "flops_per_eval": F,
             },
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU leg belongs to the one-GPU run
             line["cpu_baseline"] = cpu_baseline(periods, bounds, obs, starts, seed=7)
         print(json.dumps(line))
     if world > 1:
