@@ -30,6 +30,15 @@ sys.path.insert(0, ROOT)
 
 N_LAYERS, VPVS, N_PERIODS, CHAINS_PER_GPU = 6, 1.75, 40, 1024
 TRUE_M = np.array([0.01, 0.02, 0.04, 0.06, 0.08, 0.10, 0.2, 0.3, 0.45, 0.6, 0.8, 1.0, 1.5])
+
+
+def true_model(n_layers):
+    """The 6-layer model of the headline configuration, or one of the same span with n_layers."""
+    if n_layers == 6:
+        return TRUE_M
+    depth = np.linspace(0.01, 0.10, n_layers)
+    vs = np.interp(np.linspace(0, 1, n_layers + 1), np.linspace(0, 1, 7), TRUE_M[6:])
+    return np.concatenate([depth, vs])
 STD = 0.025
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
@@ -39,9 +48,9 @@ def flops_per_eval(rows, wave="rayleigh"):
     return 31 + 172 * (rows - 1) if wave == "rayleigh" else 8 + 25 * (rows - 1)
 
 
-def problem_inputs():
+def problem_inputs(n_layers=N_LAYERS):
     periods = np.flip(1 / np.logspace(0.3, 1.3, N_PERIODS)).copy()
-    bounds = np.array([[0.001, 0.15, 0.149]] * N_LAYERS + [[0.1, 2.0, 1.9]] * (N_LAYERS + 1))
+    bounds = np.array([[0.001, 0.15, 0.149]] * n_layers + [[0.1, 2.0, 1.9]] * (n_layers + 1))
     return periods, bounds
 
 
@@ -51,7 +60,7 @@ def prior_starts(prob, bounds, n, rng):
     out = np.empty((0, bounds.shape[0]))
     while out.shape[0] < n:
         cand = rng.uniform(bounds[:, 0], bounds[:, 1], size=(2 * n, bounds.shape[0]))
-        nl = N_LAYERS
+        nl = (bounds.shape[0] - 1) // 2
         order = np.argsort(cand[:, :nl], axis=1, kind="stable")
         cand[:, :nl] = np.take_along_axis(cand[:, :nl], order, axis=1)
         cand[:, nl:2 * nl] = np.take_along_axis(cand[:, nl:2 * nl], order, axis=1)
@@ -108,7 +117,15 @@ def main():
                     help="2 = period-parallel root search (default), 1 = wave-sequential")
     ap.add_argument("--candidates", type=int, default=2,
                     help="2 = two candidates per chain in flight (default), 1 = one")
+    # other configurations of the same path (the headline metric is the default of each)
+    ap.add_argument("--layers", type=int, default=N_LAYERS)
+    ap.add_argument("--itype", choices=["phase", "group"], default="phase")
+    ap.add_argument("--wave", choices=["rayleigh", "love"], default="rayleigh")
+    ap.add_argument("--rotation", choices=["off", "on"], default="off",
+                    help="on: rotated-frame proposals and covariance accumulation every step")
     args = ap.parse_args()
+    headline = (args.layers, args.itype, args.wave, args.rotation, args.chains) == \
+        (N_LAYERS, "phase", "rayleigh", "off", CHAINS_PER_GPU)
 
     import torch
     import torch.distributed as dist
@@ -126,19 +143,22 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
-    periods, bounds = problem_inputs()
-    B, NP, K, W = args.chains, 2 * N_LAYERS + 1, args.steps, args.warmup
+    nl = args.layers
+    periods, bounds = problem_inputs(nl)
+    B, NP, K, W = args.chains, 2 * nl + 1, args.steps, args.warmup
+    kind = dict(wave=args.wave, itype=args.itype)
     # data: true curve + N(0, std^2); the true curve comes from the product path
-    prob0 = DeviceProblem(N_LAYERS, VPVS, periods)
-    true_curve, st = prob0.forward(torch.tensor(TRUE_M[None, :], device=prob0.device))
+    prob0 = DeviceProblem(nl, VPVS, periods, **kind)
+    true_curve, st = prob0.forward(torch.tensor(true_model(nl)[None, :], device=prob0.device))
     assert int(st[0]) == 0
     np.random.seed(0)
     obs = true_curve[0].cpu().numpy() + STD * np.random.randn(N_PERIODS)
-    prob = DeviceProblem(N_LAYERS, VPVS, periods, obs, "normal", {"std": STD}, bounds)
+    prob = DeviceProblem(nl, VPVS, periods, obs, "normal", {"std": STD}, bounds, **kind)
     rng = np.random.default_rng(1000 + rank)
     starts = prior_starts(prob, bounds, B, rng)
     chains = DeviceChains(prob, starts, 0.05)
     assert int((chains.init_likelihood() != 0).sum()) == 0
+    rotate = 3 if args.rotation == "on" else 0  # identity rotation matrices: same proposals
 
     drng = np.random.default_rng(rank)  # default_rng(0) on rank 0
     total = W + K
@@ -151,7 +171,7 @@ def main():
         n_launch = 0
         for a in range(lo, hi, args.chunk):
             b = min(hi, a + args.chunk)
-            chains.steps(idx[a:b], cauchy[a:b], u_acc[a:b], want_flags=False)
+            chains.steps(idx[a:b], cauchy[a:b], u_acc[a:b], rotate=rotate, want_flags=False)
             n_launch += 1
         return n_launch
 
@@ -181,11 +201,14 @@ def main():
     acc_rate = (chains.counters[:, 0].sum().item() - acc0) / (B * K)
 
     if rank == 0:
-        F = flops_per_eval(N_LAYERS + 1)
+        F = flops_per_eval(nl + 1, args.wave)
         launch_s = kernel_ms * 1e-3 / n_launch
         achieved = lit * F / n_launch / launch_s / 1e12
         line = {
-            "metric": "MH steps/sec (whole node), 6-layer Rayleigh, 1024 chains x 40 periods",
+            "metric": "MH steps/sec (whole node), 6-layer Rayleigh, 1024 chains x 40 periods"
+                      if headline else
+                      f"MH steps/sec (whole node), {nl}-layer {args.wave} {args.itype} velocity, "
+                      f"{B} chains x 40 periods, rotation {args.rotation}",
             "value": world * B * K / elapsed,
             "unit": "MH steps/s",
             "n_gpus": world,
@@ -199,9 +222,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "configs[1]: 6-layer Rayleigh fundamental-mode phase-velocity "
-                            "inversion, 1024 independent chains x 40 periods per GPU",
-                "chains_per_gpu": B, "n_periods": N_PERIODS, "n_layers": N_LAYERS,
-                "proposal": "cauchy", "likelihood": "normal", "rotation": "off",
+                            "inversion, 1024 independent chains x 40 periods per GPU"
+                            if headline else "variant of configs[1] (see metric)",
+                "chains_per_gpu": B, "n_periods": N_PERIODS, "n_layers": nl,
+                "wave": args.wave, "itype": args.itype,
+                "proposal": "cauchy", "likelihood": "normal", "rotation": args.rotation,
                 "steps_per_launch": args.chunk, "search": args.search,
                 "candidates_in_flight": args.candidates, "acceptance_rate": round(acc_rate, 4),
             },
@@ -220,7 +245,7 @@ def main():
                 "flops_per_eval": F,
             },
         }
-        if not args.no_cpu and world == 1:  # the CPU leg belongs to the one-GPU run
+        if not args.no_cpu and world == 1 and headline:  # the CPU leg belongs to the one-GPU run
             line["cpu_baseline"] = cpu_baseline(periods, bounds, obs, starts, seed=7)
         print(json.dumps(line))
     if world > 1:
