@@ -237,8 +237,8 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": None,
-                "kernel": "mh_steps_multi_kernel<2> (with mh_steps_multi_kernel<4> beside it)"
-                if args.candidates == 2 else "mh_steps_multi_kernel<%d>" % args.candidates,
+                "kernel": "mh_steps_multi_kernel" + ("<2> (with <4> beside it)" if args.candidates == 2
+                                                   else "<%d>" % args.candidates),
                 "launch_ms": launch_s * 1e3,
                 "algorithmic_evals_per_launch": lit / n_launch,
                 "executed_evals_per_launch": ex / n_launch,
