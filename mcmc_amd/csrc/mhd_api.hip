@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) MHD_REGS void forward_kernel(mhd_problem_t p, c
     EvalCount cnt = {0, 0};
     const int st = (search == 2)
                        ? forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, out,
-                                           scratch, cnt, 0, t, false)
+                                           scratch, cnt, 0, t, 0)
                        : forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, out, scratch,
                                       cnt);
     __syncthreads();
@@ -158,6 +158,19 @@ __device__ inline void cov_accumulate_wave(const mhd_chains_t& ch, int ib, int N
 // (predict_stepwise) with 3 and 9 halvings, 3 = the wave-sequential search without prediction.
 // A curve that needed two or more repairs moves the chain one level up for the next `left`
 // forwards; a level that runs out falls back one level.  Every level returns the same curve.
+// Proposals that move the curve little start their forward model with predict_hint: those
+// whose Cauchy draw is at most hint_limit[perturbed parameter] in magnitude.  The limit adapts,
+// per chain and parameter: it grows by a quarter when predict_hint settles and drops to half the
+// draw that made it give up.  (A tuning state only: every path returns the same curve.)
+#ifndef HINT_SECANT_CAUCHY
+#define HINT_SECANT_CAUCHY 1.0
+#endif
+__device__ __forceinline__ void hint_limit_update(float* limit, int kk, double cz, int hinted)
+{
+    if (hinted == 1) limit[kk] = fminf(limit[kk] * 1.25f, 16.0f);
+    if (hinted == 2) limit[kk] = fmaxf(0.5f * (float)fabs(cz), 0.01f);
+}
+
 struct SearchPolicy {
     int level, left;
     __device__ bool predicted() const { return level < 3; }
@@ -265,6 +278,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     __shared__ double pred[MAXP];
     __shared__ double newpred[MAXP];
     __shared__ double scratch[2 * MAXP];
+    __shared__ float hlim[MAXNP];  // see hint_limit_update
 
     const int ib = blockIdx.x;
     const int lane = threadIdx.x;
@@ -276,6 +290,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
         hi[lane] = p.bounds[3 * lane + 1];
         rg[lane] = p.bounds[3 * lane + 2];
         wid[lane] = ch.width[(size_t)ib * NP + lane];
+        hlim[lane] = (float)HINT_SECANT_CAUCHY;
     }
     for (int k = lane; k < P; k += 64) {
         t[k] = p.periods[k];
@@ -310,7 +325,10 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
             build_layer_table(T, test, nl, p.vpvs, lane);
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred,
-                                       scratch, cnt, policy.stepwise(), pred, p.itype == MHD_PHASE);
+                                       scratch, cnt, policy.stepwise(), pred,
+                                       p.itype != MHD_PHASE ? 0 : (fabs(cz) <= hlim[kk] ? 2 : 1));
+                if (lane == 0)
+                    hint_limit_update(hlim, kk, cz, __builtin_amdgcn_readfirstlane(g_PS.hinted));
                 if (search == 2)
                     policy.update(1, __builtin_amdgcn_readfirstlane(g_PS.trouble) >= 2);
             } else {
@@ -511,6 +529,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     __shared__ double mn_[NG][MAXNP];   // normalised current parameters
     __shared__ double wid_[NG][MAXNP];
     __shared__ double pred_[NG][MAXP];
+    __shared__ float hlim_[NG][MAXNP];  // see hint_limit_update
     __shared__ double test[NW][MAXNP];  // candidate of each wave
     __shared__ double tmp[NW][MAXNP];
     __shared__ double newpred[NW][MAXP];
@@ -549,6 +568,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     double* mn = mn_[g];
     double* wid = wid_[g];
     double* pred = pred_[g];
+    float* hlim = hlim_[g];
 
     const long long t_begin = wall_clock64();
     const int nl = p.n_layers, NP = 2 * nl + 1, P = p.n_periods;
@@ -566,6 +586,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             m[lane] = ch.m[(size_t)ib * NP + lane];
             wid[lane] = ch.width[(size_t)ib * NP + lane];
             mn[lane] = (m[lane] - lo[lane]) / rg[lane];
+            hlim[lane] = (float)HINT_SECANT_CAUCHY;
         }
         for (int k = lane; k < P; k += 64) pred[k] = ch.pred[(size_t)ib * P + k];
     }
@@ -664,13 +685,16 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
 #ifdef MHD_PROFILE
         const long long _r0 = clock64();
 #endif
-        int jc = S, found = 0;
+        int jc = S, found = 0, kkc = 0;
+        double czc = 0.0;
         for (int j = s; j < S; ++j) {
             const int kk = idx[(size_t)j * B + ib];
             const double cz = cauchy[(size_t)j * B + ib];
             if (propose_wave(frame, mn, kk, cz, test[w], tmp[w], lane) == MHD_ST_OK &&
                 ++found == w - w0 + 1) {
                 jc = j;
+                czc = cz;
+                kkc = kk;
                 break;
             }
         }
@@ -681,8 +705,12 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             build_layer_table(T, test[w], nl, p.vpvs, lane);
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
-                                       scratch[w], cnt, policy.stepwise(), pred, p.itype == MHD_PHASE);
+                                       scratch[w], cnt, policy.stepwise(), pred,
+                                       p.itype != MHD_PHASE ? 0 : (fabs(czc) <= hlim[kkc] ? 2 : 1));
                 trouble = __builtin_amdgcn_readfirstlane(g_PS.trouble);
+                // (the waves of a chain update the limits unordered; they are heuristics)
+                if (lane == 0)
+                    hint_limit_update(hlim, kkc, czc, __builtin_amdgcn_readfirstlane(g_PS.hinted));
             } else {
                 st = forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
                                   scratch[w], cnt);
@@ -846,7 +874,13 @@ int mhd_debug_profile(unsigned long long* out16, int reset)
 {
     hipDeviceSynchronize();
     if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    return 0;
+}
+int mhd_debug_profile_hi(unsigned long long* out16)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long), 16 * sizeof(unsigned long long));
     return 0;
 }
 #endif

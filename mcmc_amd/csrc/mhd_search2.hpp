@@ -9,15 +9,19 @@
 //      lanes evaluate windows of dc-spaced abscissae for the next 1..8 periods
 //      and bracket each period's root to one dc cell (continuation in period,
 //      like the sequential search, but on approximate grids and without halving).
-//   2. predict_refine: one lane per period tightens its bracket to 1e-10 relative
-//      with the Illinois method on the exponent-tracked (smooth) secular value.
+//   2. predict_refine: one lane per period finds its root to ~1e-12 relative with
+//      secant steps on the exponent-tracked (smooth) secular value.
+//      (predict_hint does 1 and 2 in one when the curve of a similar model is
+//      known and the new curve is close to it: secant steps from that curve, all
+//      periods at once.)
 //   3. replay: the sequential algorithm is executed with signs inferred from the
-//      brackets; no evaluations (a point that falls inside a bracket is really
-//      evaluated).  Every abscissa it consumes is recorded.
-//   4. verify: the lanes really evaluate every recorded abscissa.  If all signs
-//      agree, the replay WAS the sequential algorithm, bit for bit.  At the first
-//      disagreement the periods before it are exact and the rest of the curve is
-//      recomputed by the wave-sequential search of mhd_device.hpp.
+//      roots; no evaluations.  What it did for each period is kept as a summary
+//      from which every abscissa it consumed can be regenerated.
+//   4. verify: the lanes really evaluate every abscissa the replay consumed.  If
+//      all signs agree, the replay WAS the sequential algorithm, bit for bit.  At
+//      the first disagreement the periods before it are exact; that period is
+//      redone by the wave-sequential search of mhd_device.hpp and the rest is
+//      replayed (or predicted) again.
 //
 // Stages 1-2 are only a predictor: any failure there costs time, never accuracy.
 #pragma once
@@ -42,6 +46,7 @@ struct PredictScratch {
     int rmeta[MAXP];
     unsigned short roff[MAXP + 1];  // number of abscissae of the pass before the period's
     int trouble;  // repairs the last predicted curve needed (9: the predictor gave up)
+    int hinted;   // predict_hint for the last curve: 0 not tried, 1 settled, 2 gave up
 };
 
 static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
@@ -50,17 +55,24 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
     (*reinterpret_cast<PredictScratch*>(mhd_wave_lds + (threadIdx.x >> 6) * WAVE_LDS_BYTES + \
                                         WAVE_LDS_SEARCH_OFFSET))
 
+// A secant iterate x(n+1) is within about C |x(n+1)-x(n)| |x(n+1)-x(n-1)| of the root; with this
+// bound on the product it is taken as the root without being evaluated (C, the curvature over
+// twice the slope, is some tens per km/s; the replay wants 1e-12)
+#define ROOT_ERR_PRODUCT 2.0e-14
+
 #pragma clang fp contract(off)
 
 #ifdef MHD_PROFILE
-__device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_prof[32];
 __device__ unsigned long long g_times[4096];
 __device__ unsigned long long g_blk[1024 * 8];
 #define PROF_T0 long long _t0 = clock64();
 #define PROF_ADD(i) { long long _t1 = clock64(); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_prof[i], (unsigned long long)(_t1 - _t0)); if (blockIdx.x < 1024) g_blk[blockIdx.x * 8 + i] += (unsigned long long)(_t1 - _t0); } _t0 = _t1; }
+#define HINT_WHY(i) if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[i], 1ull);
 #else
 #define PROF_T0
 #define PROF_ADD(i)
+#define HINT_WHY(i)
 #endif
 
 __device__ __forceinline__ int mask_sign(unsigned long long neg, unsigned long long pos, int bit)
@@ -331,9 +343,6 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
     if (lane == 0) {
         atomicAdd(&g_prof[14], (unsigned long long)rounds);
         atomicAdd(&g_prof[15], 1ull);
-        atomicAdd(&g_prof[13], (unsigned long long)(use_hint && hint_ok));
-        atomicAdd(&g_prof[11], (unsigned long long)prof_first);
-        atomicAdd(&g_prof[12], (unsigned long long)prof_shaped);
     }
 #endif
     return P;
@@ -432,23 +441,55 @@ __device__ MHD_NOINLINE void predict_refine(int wave, const double* t, int kbeg,
         const int sa = sgni(fa);
         int sb = sgni(fb);
         bool done = !active || sa == sb || sa == 0 || sb == 0;
-        int side = 0;
+        // Secant steps on the two latest iterates (x0, x1), kept inside the bracket [a, b] of
+        // evaluated points (a step that leaves it becomes an Illinois step on the bracket).
+        // The errors fall like e(n+1) ~ C e(n) e(n-1), so when a step is shorter than 1e-9 a the
+        // NEXT iterate is far closer to the root than the 1e-12 that the replay needs, and is
+        // taken without being evaluated: the replay infers signs from it alone and the
+        // verification pass checks every one of them anyway.
+        double x0 = a, f0 = fa, x1 = b, f1 = fb, root = 0.5 * (a + b);
+        int e0 = ea, e1 = eb, side = 0;
         for (int it = 0; it < 48; ++it) {
-            const double tol = 1.0e-10 * a;
-            if (b - a <= tol) done = true;
+            double x = root;
+            if (!done) {
+                auto secant = [](double xa, double fxa, int exa, double xb, double fxb, int exb) {
+                    int de = exb - exa;
+                    de = de > 1000 ? 1000 : (de < -1000 ? -1000 : de);
+                    const double rho = ldexp(fxb / fxa, de);
+                    return xa + (xb - xa) / (1.0 - rho);
+                };
+                x = secant(x0, f0, e0, x1, f1, e1);
+                const double w = b - a;
+                const double mgn = 1.0e-3 * w;
+                bool plain_step = true;
+                if (!(x > a + mgn && x < b - mgn)) {
+                    x = secant(a, fa, ea, b, fb, eb);  // Illinois-weighted ends
+                    if (!(x > a + mgn)) x = a + mgn;
+                    if (!(x < b - mgn)) x = b - mgn;
+                    plain_step = false;
+                }
+                if (it > 0 && (fabs(x - x1) <= 1.0e-9 * a ||
+                               (plain_step && fabs(x - x1) * fabs(x - x0) <= ROOT_ERR_PRODUCT))) {
+                    root = x;
+                    done = true;
+                }
+                if (w <= 1.0e-12 * a) {
+                    root = 0.5 * (a + b);
+                    done = true;
+                }
+            }
             const unsigned long long todo = __ballot(!done);
             if (todo == 0ull) break;
             cnt.exec += (unsigned long long)__popcll(todo);
             if (!done) {
-                int de = eb - ea;
-                de = de > 1000 ? 1000 : (de < -1000 ? -1000 : de);
-                const double rho = ldexp(fb / fa, de);  // < 0
-                double x = a + (b - a) / (1.0 - rho);
-                const double w = b - a;
-                const double mgn = fmax(0.25 * tol, 1.0e-3 * w);
-                if (!(x > a + mgn)) x = a + mgn;
-                if (!(x < b - mgn)) x = b - mgn;
                 const SecVal v = eval_secular(wave, omega, x);
+                x0 = x1;
+                f0 = f1;
+                e0 = e1;
+                x1 = x;
+                f1 = v.m;
+                e1 = v.e;
+                root = x;
                 if (sgni(v.m) == sa) {
                     a = x;
                     fa = v.m;
@@ -466,13 +507,153 @@ __device__ MHD_NOINLINE void predict_refine(int wave, const double* t, int kbeg,
             }
         }
         if (active) {
-            S.lo[k] = a;
-            S.hi[k] = b;
+            const bool bracketed = sa != sb && sa != 0 && sb != 0;
+            S.lo[k] = bracketed ? root : a;
+            S.hi[k] = bracketed ? root : b;
             S.slo[k] = (signed char)sa;
             S.shi[k] = (signed char)sb;
         }
     }
     wave_sync();
+}
+
+// longest extrapolation step of predict_hint, in dc
+#ifndef HINT_STEP_MAX
+#define HINT_STEP_MAX 4.0
+#endif
+
+// ---- stages 1 and 2 in one, from a hint ---------------------------------------------
+// All periods at once, one lane each: secant iterations started at the hint's value for the
+// period (the curve of a similar model) find the nearby root to ~1e-12 relative in five to
+// seven rounds, without the dc lattice.  Whether that root is the one the sequential search
+// arrives at is for the verification to find out, as with predict_coarse.  Returns P, or -1 when
+// a period does not settle (the caller then uses predict_coarse): an iterate leaves
+// (floor, ceiling) or strays more than 16 dc from the hint, or the iteration is not done after
+// ten rounds.
+__device__ MHD_NOINLINE int predict_hint(int wave, const double* t, int P, double tscale,
+                                         double dc, const double* hint, EvalCount& cnt)
+{
+    PredictScratch& S = g_PS;
+    const int lane = threadIdx.x & 63;
+    const double cc = g_T.cc, top = g_T.betmx + dc;
+    for (int kb = 0; kb < P; kb += 64) {
+        const int k = kb + lane;
+        const bool active = k < P;
+        const double h = hint[active ? k : 0];
+        const double omega = TWOPI / (t[active ? k : 0] / tscale);
+        bool done = !active, failed = false;
+        if (active && !(h > cc + dc && h < top - dc)) failed = true;
+        if (__ballot(failed)) return -1;
+        // iterates (x0, x1), the latest in x1; [a, b] brackets the root once a sign change
+        // has been seen (sa = sign at a, below the root)
+        double x0 = h, f0 = 0.0, x1 = h, f1 = 0.0, a = 0.0, b = 0.0, fa = 0.0, fb = 0.0;
+        double root = h, x = h;
+        int e0 = 0, e1 = 0, ea = 0, eb = 0, sa = 0, side = 0;
+        bool bracketed = false;
+        auto secant = [](double xa, double fxa, int exa, double xb, double fxb, int exb) {
+            int de = exb - exa;
+            de = de > 1000 ? 1000 : (de < -1000 ? -1000 : de);
+            const double rho = ldexp(fxb / fxa, de);
+            return xa + (xb - xa) / (1.0 - rho);
+        };
+        for (int it = 0; it < 11; ++it) {
+            // the next abscissa, computed by every lane (no divergent flow before the votes)
+            if (it == 0) {
+                x = h;
+            } else if (it == 1) {
+                x = h + 0.5 * dc;
+            } else {
+                double xs = secant(x0, f0, e0, x1, f1, e1);
+                // bracketed: inside the bracket, else an Illinois step on its ends
+                const double mgn = 1.0e-3 * (b - a);
+                const bool inside = xs > a + mgn && xs < b - mgn;
+                double xi = secant(a, fa, ea, b, fb, eb);
+                xi = (xi > a + mgn) ? xi : a + mgn;
+                xi = (xi < b - mgn) ? xi : b - mgn;
+                // not bracketed: an extrapolation; a long one means a large shift (or a poor
+                // linear model), where the windows of predict_coarse are the better tool
+                const double xn = bracketed ? (inside ? xs : xi) : xs;
+                const bool bad = !(xn > cc && xn < top) ||
+                                 (!bracketed && !(fabs(xn - x1) <= HINT_STEP_MAX * dc)) ||
+                                 !(fabs(xn - h) <= 16.0 * dc);
+                const bool conv = fabs(xn - x1) <= 1.0e-9 * x1 ||
+                                  (it > 2 && (inside || !bracketed) &&
+                                   fabs(xn - x1) * fabs(xn - x0) <= ROOT_ERR_PRODUCT);
+                failed = failed || (!done && (bad || it >= 10));
+                if (!done) {
+                    x = xn;
+                    root = conv ? xn : root;
+                }
+                done = done || conv;
+            }
+            const unsigned long long nfail = __ballot(failed);
+            const unsigned long long todo = __ballot(!done);
+            if (nfail != 0ull) {
+                HINT_WHY(16)
+#ifdef MHD_PROFILE
+                if (lane == 0) atomicAdd(&g_prof[19], (unsigned long long)it);
+#endif
+                return -1;
+            }
+            if (todo == 0ull) {
+                HINT_WHY(18)
+#ifdef MHD_PROFILE
+                if (lane == 0) atomicAdd(&g_prof[17], (unsigned long long)it);
+#endif
+                break;
+            }
+            cnt.exec += (unsigned long long)__popcll(todo);
+            SecVal v = {0.0, 0};
+            if (!done) v = eval_secular(wave, omega, x);
+            const int sv = sgni(v.m);
+            if (!done) {
+                if (sv == 0) failed = true;
+                if (bracketed) {
+                    if (sv == sa) {
+                        a = x;
+                        fa = v.m;
+                        ea = v.e;
+                        if (side == -1) fb *= 0.5;
+                        side = -1;
+                    } else {
+                        b = x;
+                        fb = v.m;
+                        eb = v.e;
+                        if (side == +1) fa *= 0.5;
+                        side = +1;
+                    }
+                } else if (it > 0 && sv != sgni(f1)) {
+                    // the first sign change: between the latest iterate and this one
+                    bracketed = true;
+                    const bool up = x > x1;
+                    a = up ? x1 : x;
+                    fa = up ? f1 : v.m;
+                    ea = up ? e1 : v.e;
+                    b = up ? x : x1;
+                    fb = up ? v.m : f1;
+                    eb = up ? v.e : e1;
+                    sa = sgni(fa);
+                }
+                x0 = x1;
+                f0 = f1;
+                e0 = e1;
+                x1 = x;
+                f1 = v.m;
+                e1 = v.e;
+            }
+        }
+        if (active) {
+            // never bracketed: every iterate lies on one side of the root
+            const int s1 = sgni(f1);
+            const int slo = bracketed ? sa : (root > x1 ? s1 : -s1);
+            S.lo[k] = root;
+            S.hi[k] = root;
+            S.slo[k] = (signed char)slo;
+            S.shi[k] = (signed char)-slo;
+        }
+    }
+    wave_sync();
+    return P;
 }
 
 // ---- stage 3 ----------------------------------------------------------------
@@ -569,11 +750,11 @@ __device__ __forceinline__ double replay_abscissa(int k, int q, double dc)
 // Fundamental-mode phase velocities c[0..P-1] (LDS) of the table in g_T, bit-identical to
 // phase_curve_wave(..., mode = 0, ...).  Returns MHD_ST_OK or MHD_ST_NOROOT.
 // stepwise > 0: predict with predict_stepwise(levels = stepwise) instead of predict_coarse.
-// hint: see predict_coarse.
+// hint: see predict_coarse; use_hint 0: none, 1: for predict_coarse, 2: predict_hint first.
 __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int P, double tscale,
                                                   double dc, double* c, EvalCount& cnt,
                                                   int stepwise, const double* hint,
-                                                  bool use_hint)
+                                                  int use_hint)
 {
     const LayerTable& T = g_T;
     PredictScratch& S = g_PS;
@@ -581,17 +762,30 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
     const int lane = threadIdx.x & 63;
     dc = fabs(dc);
     PROF_T0
-    int nP = stepwise ? predict_stepwise(wave, t, 0, P, tscale, dc, 0.0, 0, stepwise, cnt)
-                      : predict_coarse(wave, t, 0, P, tscale, dc, 0.0, 0, hint, use_hint, cnt);
-    PROF_ADD(0)
-    S.trouble = (nP < 0) ? 9 : 0;
-    if (nP < 0) {
-        const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt);
-        PROF_ADD(5)
-        return r;
+    int nP = -1;
+    S.hinted = 0;
+    if (!stepwise && use_hint == 2) {
+        nP = predict_hint(wave, t, P, tscale, dc, hint, cnt);
+        S.hinted = nP < 0 ? 2 : 1;
+        PROF_ADD(0)
+#ifdef MHD_PROFILE
+        if (lane == 0) { atomicAdd(&g_prof[11], 1ull); atomicAdd(&g_prof[12], (unsigned long long)(nP < 0)); }
+#endif
     }
-    predict_refine(wave, t, 0, nP, tscale, cnt, stepwise > 0);
-    PROF_ADD(1)
+    if (nP < 0) {
+        nP = stepwise ? predict_stepwise(wave, t, 0, P, tscale, dc, 0.0, 0, stepwise, cnt)
+                      : predict_coarse(wave, t, 0, P, tscale, dc, 0.0, 0, hint, use_hint != 0, cnt);
+        PROF_ADD(0)
+        if (nP < 0) {
+            S.trouble = 9;
+            const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt);
+            PROF_ADD(5)
+            return r;
+        }
+        predict_refine(wave, t, 0, nP, tscale, cnt, stepwise > 0);
+        PROF_ADD(1)
+    }
+    S.trouble = 0;
 
     const double cc = T.cc, betmx = T.betmx, cm = T.cc;
     int s1st = 0, kstart = 0, repairs = 0;
@@ -705,8 +899,8 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             // the sequential search moved to another branch than the predictor's: predict the
             // remaining periods again, continuing from the root it found
             nP = stepwise ? predict_stepwise(wave, t, kstart, P, tscale, dc, cr, s1st, stepwise, cnt)
-                          : predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, hint, use_hint,
-                                           cnt);
+                          : predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, hint,
+                                           use_hint != 0, cnt);
             PROF_ADD(0)
             if (nP < 0) {
                 const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
@@ -752,18 +946,31 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
 __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode, int itype,
                                         const double* t, int P, double dc, double dt,
                                         double* vel, double* scratch, EvalCount& cnt,
-                                        int stepwise, const double* hint, bool use_hint)
+                                        int stepwise, const double* hint, int use_hint)
 {
     // (hint is never tested against null: a null test of a pointer into LDS trips the compiler;
     // without a hint the callers pass any valid pointer and use_hint = false)
     if (mode != 0)
         return forward_wave(T, wave, mode, itype, t, P, dc, dt, vel, scratch, cnt);
-    if (itype == MHD_PHASE) return phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt, stepwise, hint, use_hint);
+    if (itype == MHD_PHASE) {
+        const int st = phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt, stepwise, hint, use_hint);
+#ifdef MHD_PROFILE
+        if (use_hint && st == MHD_ST_OK) {
+            // largest shift of a root against the hint, in dc: buckets <1/4, <1/2, <1, <2, ... 
+            double mx = 0.0;
+            for (int k = 0; k < P; ++k) mx = fmax(mx, fabs(vel[k] - hint[k]) / fabs(dc));
+            int bkt = 0;
+            for (double lim = 0.25; mx >= lim && bkt < 10; lim *= 2.0) ++bkt;
+            if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[21 + bkt], 1ull);
+        }
+#endif
+        return st;
+    }
     double* c1 = scratch;
     double* c2 = scratch + P;
-    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt, stepwise, t, false);
+    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt, stepwise, t, 0);
     if (st != MHD_ST_OK) return st;
-    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt, stepwise, t, false);
+    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt, stepwise, t, 0);
     if (st != MHD_ST_OK) return st;
     for (int k = 0; k < P; ++k) {
         if (c1[k] > 0.0 && c2[k] > 0.0) {

@@ -62,3 +62,46 @@ for i in range(1024):
 print("distinct CUs seen:",len(occ),"waves resident at start: total",sum(occ.values()),"histogram of waves per CU:",sorted(collections.Counter(occ.values()).items()))
 print("CUs with a quad: waves per CU histogram:",sorted(collections.Counter(occ[k] for k in quads).items()), "quads per CU:",sorted(collections.Counter(quads.values()).items()))
 print("xcc distribution of early waves:",sorted(collections.Counter({x:sum(v for k,v in occ.items() if k//1000==x) for x in range(8)}).items()))
+
+# what the best assignment of candidates could reach: smallest T with sum of waves <= 2048
+def need(T, cons):
+    tot = 0
+    for c in cost:
+        for J in sorted(cons):
+            if c / cons[J] <= T:
+                tot += J; break
+        else:
+            return 10**9
+    return tot
+for name, cons_ in (("1,2,4", {1:1.0,2:1.65,4:2.35}), ("1,2,3,4", {1:1.0,2:1.65,3:2.07,4:2.35}), ("1,2,3,4,8", {1:1.0,2:1.65,3:2.07,4:2.35,8:2.9}), ("1,2,4,8", {1:1.0,2:1.65,4:2.35,8:2.9})):
+    for budget in (2048, 1960):
+        T = 1000.0
+        for cand in np.arange(150, 900, 2.0):
+            if need(cand*100.0, cons_) <= budget:
+                T = cand; break
+        print("classes", name, "budget", budget, "-> best predicted makespan (ticks/100 = us/step):", T)
+print("cost ticks percentiles (one candidate) p1 p10 p50 p90 p99 max:", np.percentile(cost,[1,10,50,90,99,100]).round())
+
+ratio = act_us / pred_us
+print("actual/predicted by xcc:", [(x, round(float(np.median(ratio[xcc==x])),3), round(float(ratio[xcc==x].max()),2)) for x in range(8)])
+worst = np.argsort(ratio)[-12:]
+print("worst ratios:", [(int(i), "J%d"%cls[i], "xcc%d se%d sh%d cu%d"%(xcc[i],se[i],sh[i],cu[i]), round(float(ratio[i]),2), int(act_us[i]), int(st[i])) for i in worst])
+slowest = np.argsort(act_us)[-12:]
+print("slowest:", [(int(i), "J%d"%cls[i], "xcc%d se%d sh%d cu%d"%(xcc[i],se[i],sh[i],cu[i]), round(float(ratio[i]),2), int(act_us[i]), int(pred_us[i])) for i in slowest])
+# neighbours on the same CU: their mean duration against the chain's own
+bykey = collections.defaultdict(list)
+for i in range(1024): bykey[key[i]].append(i)
+nb = np.array([np.mean([dur[j] for j in bykey[key[i]]]) for i in range(1024)])
+print("correlation of a chain's actual/predicted with the mean duration of the chains on its CU: %.3f" % np.corrcoef(ratio, nb)[0,1])
+
+pos = np.full(1024, -1)
+for pblk in range(ns):
+    for w_ in range(2): pos[order[B - 2*ns + 2*pblk + w_]] = pblk
+for pblk in range(ns, B - n4 - ns): pos[order[n4 + pblk - ns]] = pblk
+for q in range(n4): pos[order[q]] = 10000 + q
+shown = 0
+for kk_, members in sorted(bykey.items()):
+    if shown < 10 and all(early[j] for j in members):
+        print("CU", kk_, "block positions", sorted(int(pos[j]) for j in members)); shown += 1
+np.save(os.path.join(ROOT, "gpurun_out", "cost.npy"), cost)
+np.save(os.path.join(ROOT, "gpurun_out", "act_us.npy"), act_us)
