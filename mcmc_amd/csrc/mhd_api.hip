@@ -424,24 +424,49 @@ __device__ __constant__ float SCHED_CONSUMED[5] = {0.0f, 1.0f, 1.65f, 2.07f, 2.3
 
 struct SchedView {
     float* cost;  // [B]
-    int* n4;      // [0] n4, [1] number of split workgroups (+ padding)
+    int* n4;      // [0] n4, [1] number of split workgroups, [2..3] the deadline of the launch,
+                  // [4] n4 of the call's first launch, [5] chains the last launch found unfinished
+                  // (diagnostics), [6..7] unused
     int* order;   // [B]
+    int* progress;         // [B] steps of the current call each chain has done
     unsigned char* level;  // [B] SearchPolicy level each chain ended its last launch with
 };
 
-__host__ __device__ inline int sched_cap4(int B) { return B / 8 > 0 ? B / 8 : 1; }
+__host__ __device__ inline int sched_cap4(int B, int phase)
+{
+    const int c = phase == 0 ? B / 8 : B / 2;
+    return c > 0 ? c : 1;
+}
 
 __host__ __device__ inline SchedView sched_view(void* buf, int B)
 {
     SchedView v;
     v.cost = (float*)buf;
     v.n4 = (int*)(v.cost + B);
-    v.order = v.n4 + 4;
-    v.level = (unsigned char*)(v.order + B);
+    v.order = v.n4 + 8;
+    v.progress = v.order + B;
+    v.level = (unsigned char*)(v.progress + B);
     return v;
 }
 
-__global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B)
+// One call of mhd_mh_steps is made of SCHED_PHASES launches.  All but the last end at a deadline
+// (every chain stops after the round it is in and leaves the number of steps it has done in
+// `progress`); the next launch gives the chains their candidates anew, by the work each has
+// left: as the cheap chains finish, the places they leave go to the expensive ones, which then
+// run with four candidates instead of two.  phase 0 also resets `progress`.
+#ifndef SCHED_PHASES_N
+#define SCHED_PHASES_N 2
+#endif
+constexpr int SCHED_PHASES = SCHED_PHASES_N;
+#ifndef PHASE_DEADLINE_LATER
+#define PHASE_DEADLINE_LATER 1.0f  // later deadlines, in units of the median unfinished chain's
+#endif
+#ifndef PHASE_DEADLINE_FRACTION
+#define PHASE_DEADLINE_FRACTION 0.9f  // first deadline, in units of the median chain's expected time
+#endif
+
+__global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S, int phase,
+                                                        int slots)
 {
     __shared__ float key[SCHED_MAX_CHAINS];
     __shared__ int val[SCHED_MAX_CHAINS];
@@ -452,10 +477,13 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B)
     if (threadIdx.x == 0) unknown = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float c = i < B ? v.cost[i] : -1.0f;
+        float c = i < B ? v.cost[i] : -1.0f;
+        if (i < B && !(c > 0.0f)) unknown = 1;
+        if (i < B && phase == 0) v.progress[i] = 0;
+        // later phases: by the work that is left
+        if (i < B && phase > 0) c *= (float)(S - v.progress[i]);
         key[i] = c;
         val[i] = i < B ? i : -1;
-        if (i < B && !(c > 0.0f)) unknown = 1;
     }
     __syncthreads();
     // bitonic sort, descending by cost (ties: by chain index, so that the order is definite)
@@ -485,9 +513,10 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B)
     // perfectly, and one that has to wait for room starts when the first chains are done.
     if (threadIdx.x == 0) {
         int n4 = 0, nsplit = 0;
-        if (!unknown) {
+        unsigned long long deadline = 0;
+        if (!unknown && phase == 0) {
             const float with4 = key[0] / SCHED_CONSUMED[4];
-            const int cap = sched_cap4(B);
+            const int cap = sched_cap4(B, 0);
             while (n4 < cap && key[n4] / SCHED_CONSUMED[2] > SCHED_MARGIN * with4) {
                 const int ns = n4 + 1 + SCHED_SPARE + (n4 + 1) / 2;
                 if (n4 + 1 + 2 * ns >= B) break;
@@ -496,9 +525,30 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B)
                 ++n4;
                 nsplit = ns;
             }
+            if (PHASE_DEADLINE_FRACTION > 0.0f)
+                deadline = (unsigned long long)wall_clock64() +
+                           (unsigned long long)(PHASE_DEADLINE_FRACTION * key[B / 2] * (float)S /
+                                                SCHED_CONSUMED[2]);
+        } else if (!unknown) {
+            // the chains with work left (they come first in the order): four candidates for as
+            // many of them as the wave slots allow beside two for the others
+            int left = 0;
+            while (left < B && key[left] > 0.0f) ++left;
+            v.n4[5] = left;
+            const int room = (slots - 2 * left) / 2;
+            n4 = room < 0 ? 0 : (room < left ? room : left);
+            const int cap = sched_cap4(B, phase);
+            if (n4 > cap) n4 = cap;
+            if (phase < SCHED_PHASES - 1 && left > 0)
+                deadline = (unsigned long long)wall_clock64() +
+                           (unsigned long long)(PHASE_DEADLINE_LATER * key[left / 2] /
+                                                SCHED_CONSUMED[left / 2 < n4 ? 4 : 2]);
         }
         v.n4[0] = n4;
         v.n4[1] = nsplit;
+        if (phase == 0) v.n4[4] = n4;
+        v.n4[2] = (int)(deadline & 0xFFFFFFFFull);
+        v.n4[3] = (int)(deadline >> 32);
     }
     for (int i = threadIdx.x; i < B; i += blockDim.x) v.order[i] = val[i];
 }
@@ -534,7 +584,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     __shared__ double tmp[NW][MAXNP];
     __shared__ double newpred[NW][MAXP];
     __shared__ double scratch[NW][2 * MAXP];
-    __shared__ int r_step[NW], r_st[NW], r_trouble[NW];
+    __shared__ int r_step[NW], r_st[NW], r_trouble[NW], r_stop[NW];
     __shared__ double r_logL[NW];
     __shared__ unsigned long long r_lit[NW];
 
@@ -556,6 +606,8 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             ib = split ? B - 2 * nsplit + 2 * ib + w : n4 + ib - nsplit;
         }
         ib = sv.order[ib];
+        // nothing left of this call for the chain (a later phase): the workgroup is done
+        if (!split && sv.progress[ib] >= S) return;
     }
     const int g = split ? w : 0;    // chain slot of this wave in the workgroup
     const int w0 = split ? w : 0;   // first wave of this wave's chain
@@ -678,7 +730,16 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         return acc;
     };
 
+    // a scheduled launch goes on where the call's earlier launches left the chain and ends at
+    // the deadline, if there is one
     int s = 0;
+    unsigned long long deadline = 0;
+    if (scheduled) {
+        const SchedView sv = sched_view(ch.sched, B);
+        s = sv.progress[ib];
+        deadline = (unsigned long long)(unsigned)sv.n4[2] | ((unsigned long long)(unsigned)sv.n4[3] << 32);
+    }
+    const int s_begin = s;
     while (s < S) {
         // ---- this wave's candidate: the (w-w0+1)-th proposal from step s on that passes the
         // bounds
@@ -765,7 +826,10 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         }
 #endif
         if (search == 2) policy.update(ran, trouble2);
+        if (writer && lane == 0)
+            r_stop[w0] = deadline != 0 && (unsigned long long)wall_clock64() >= deadline;
         group_sync();
+        if (r_stop[w0]) break;
     }
 
 #ifdef MHD_PROFILE
@@ -773,10 +837,15 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
 #endif
     if (writer && lane == 0 && keeps) {
         if (search == 2) sched_view(ch.sched, B).level[ib] = (unsigned char)policy.level;
-        float* cost = sched_view(ch.sched, B).cost;
-        const float now = (float)(wall_clock64() - t_begin) * SCHED_CONSUMED[nw] / (float)S;
-        const float old = cost[ib];
-        cost[ib] = old > 0.0f ? old + SCHED_GAIN * (now - old) : now;
+        if (scheduled) sched_view(ch.sched, B).progress[ib] = s;
+        if (s > s_begin) {
+            // (a launch that did only part of the call's steps counts by that part)
+            float* cost = sched_view(ch.sched, B).cost;
+            const float done = (float)(s - s_begin);
+            const float now = (float)(wall_clock64() - t_begin) * SCHED_CONSUMED[nw] / done;
+            const float old = cost[ib];
+            cost[ib] = old > 0.0f ? old + SCHED_GAIN * (done / (float)S) * (now - old) : now;
+        }
     }
     if (writer) {
         if (lane < NP) ch.m[(size_t)ib * NP + lane] = m[lane];
@@ -842,7 +911,7 @@ extern "C" {
 size_t mhd_sched_bytes(int32_t B)
 {
     if (B < 0) B = 0;
-    return sizeof(float) * (size_t)B + sizeof(int) * (4 + (size_t)B) + (size_t)B + 64;
+    return sizeof(float) * (size_t)B + sizeof(int) * (8 + 2 * (size_t)B) + (size_t)B + 64;
 }
 
 int mhd_abi_version(void) { return MHD_ABI_VERSION; }
@@ -972,21 +1041,30 @@ int mhd_mh_steps(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t 
         // the others fill the GPU), the others beside them on a second stream
         SideStream* side = side_stream();
         if (!side) return MHD_EHIP;
-        hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, chains->sched, B);
-        hipError_t e = hipEventRecord(side->fork, s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
-        if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps fork");
-        hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(sched_cap4(B)), dim3(256),
-                           4 * WAVE_LDS_BYTES, s, *prob, *chains, B, n_steps, idx, cauchy, u_acc,
-                           T, rotate, accepted, status, hist_every, hist_m, hist_logL, hist_pred,
-                           ne, g_search, 1);
-        hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES,
-                           side->stream, *prob, *chains, B, n_steps, idx, cauchy, u_acc, T,
-                           rotate, accepted, status, hist_every, hist_m, hist_logL, hist_pred, ne,
-                           g_search, 1);
-        e = hipEventRecord(side->join, side->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s, side->join, 0);
-        if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps join");
+        int dev = 0, cus = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess)
+            e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps device");
+        const int slots = cus * 8;  // two waves of these kernels per SIMD
+        for (int phase = 0; phase < SCHED_PHASES; ++phase) {
+            hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, chains->sched, B,
+                               n_steps, phase, slots);
+            e = hipEventRecord(side->fork, s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
+            if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps fork");
+            hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(sched_cap4(B, phase)), dim3(256),
+                               4 * WAVE_LDS_BYTES, s, *prob, *chains, B, n_steps, idx, cauchy,
+                               u_acc, T, rotate, accepted, status, hist_every, hist_m, hist_logL,
+                               hist_pred, ne, g_search, 1);
+            hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES,
+                               side->stream, *prob, *chains, B, n_steps, idx, cauchy, u_acc, T,
+                               rotate, accepted, status, hist_every, hist_m, hist_logL, hist_pred,
+                               ne, g_search, 1);
+            e = hipEventRecord(side->join, side->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, side->join, 0);
+            if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps join");
+        }
     } else if (g_candidates == 2 && !sample_prior) {
         hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES, s,
                            *prob, *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, accepted,

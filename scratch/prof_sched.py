@@ -32,7 +32,7 @@ print("latest finishers:", [(int(i), int(st[i]), int(en[i])) for i in slow])
 
 ch=_keep[-1]; B=1024
 raw=ch.sched.cpu().numpy()
-cost=raw[:4*B].view(np.float32).astype(np.float64); n4=int(raw[4*B:4*B+4].view(np.int32)[0]); ns=int(raw[4*B+4:4*B+8].view(np.int32)[0]); order=raw[4*B+16:4*B+16+4*B].view(np.int32)
+cost=raw[:4*B].view(np.float32).astype(np.float64); n4=int(raw[4*B:4*B+4].view(np.int32)[0]); ns=int(raw[4*B+4:4*B+8].view(np.int32)[0]); order=raw[4*B+32:4*B+32+4*B].view(np.int32); print('header', raw[4*B:4*B+32].view(np.int32)); print('first-launch n4', int(raw[4*B+16:4*B+20].view(np.int32)[0]), 'chains unfinished at the last launch', int(raw[4*B+20:4*B+24].view(np.int32)[0]))
 print("n4",n4,"nsplit",ns,"chains starting later than 1 ms:",int((st>1000).sum()))
 # cost is ticks per step at one candidate; predicted us/step per class
 cons={1:1.0,2:1.65,4:2.35}
@@ -105,3 +105,16 @@ for kk_, members in sorted(bykey.items()):
         print("CU", kk_, "block positions", sorted(int(pos[j]) for j in members)); shown += 1
 np.save(os.path.join(ROOT, "gpurun_out", "cost.npy"), cost)
 np.save(os.path.join(ROOT, "gpurun_out", "act_us.npy"), act_us)
+
+rawb = np.array(list(bb), dtype=np.uint64).reshape(1024, 8)
+rounds = (rawb[:, 7] >> np.uint64(40)).astype(np.float64); fw = ((rawb[:, 7] >> np.uint64(20)) & np.uint64(0xFFFFF)).astype(np.float64)
+cyc = rawb[:, :5].astype(np.float64); mism = rawb[:, 6].astype(np.float64)
+cnt_ = ch.counters.cpu().numpy()
+print("top chains by cost: (chain, cost us, class, forwards/step, kcycles/forward by phase coarse/refine/replay/verify/repair, mismatches/forward, accept rate, bounds rate)")
+for i in np.argsort(-cost)[:14]:
+    tot = cnt_[i, 0] + cnt_[i, 1]
+    print("  %4d %5.0f J%d fw/step %.2f | %s | mism %.2f | acc %.3f bounds %.3f" % (i, cost[i] / 100, cls[i], fw[i] / 750, " ".join("%4.0f" % (c / max(fw[i], 1) / 1000) for c in cyc[i]), mism[i] / max(fw[i], 1), cnt_[i, 0] / tot, cnt_[i, 2] / tot))
+print("median chains:")
+for i in np.argsort(-cost)[510:514]:
+    tot = cnt_[i, 0] + cnt_[i, 1]
+    print("  %4d %5.0f J%d fw/step %.2f | %s | mism %.2f | acc %.3f bounds %.3f" % (i, cost[i] / 100, cls[i], fw[i] / 750, " ".join("%4.0f" % (c / max(fw[i], 1) / 1000) for c in cyc[i]), mism[i] / max(fw[i], 1), cnt_[i, 0] / tot, cnt_[i, 2] / tot))

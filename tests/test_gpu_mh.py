@@ -153,7 +153,7 @@ def test_scheduled_launches_do_not_change_the_chains(oracle, candidates):
             acc.append(torch.cat([out["accepted"].flatten().to(torch.float64),
                                   out["hist_logL"].flatten()]))
             if scheduled:
-                n4_seen = max(n4_seen, int(ch.sched[4 * B:4 * B + 4].view(torch.int32)[0]))
+                n4_seen = max(n4_seen, int(ch.sched[4 * B + 16:4 * B + 20].view(torch.int32)[0]))
         results.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(),
                         torch.cat(acc), int(ch.n_evals[0])))
     a, b = results
