@@ -69,6 +69,7 @@ __global__ __launch_bounds__(64) MHD_REGS void secular_kernel(mhd_problem_t p, c
 {
     // one wave per query keeps the table code identical to the other kernels
     LayerTable& T = g_T;
+    if ((threadIdx.x & 63) == 0) g_PS.prof_slot = (int)blockIdx.x;
     __shared__ double m[MAXNP];
     const int q = blockIdx.x;
     if (q >= N) return;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(64) MHD_REGS void forward_kernel(mhd_problem_t p, c
                                                      unsigned long long* n_evals, int search)
 {
     LayerTable& T = g_T;
+    if ((threadIdx.x & 63) == 0) g_PS.prof_slot = (int)blockIdx.x;
     __shared__ double m[MAXNP];
     __shared__ double t[MAXP];
     __shared__ double out[MAXP];
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     unsigned long long* n_evals, int search)
 {
     LayerTable& T = g_T;
+    if ((threadIdx.x & 63) == 0) g_PS.prof_slot = (int)blockIdx.x;
     __shared__ double m[MAXNP];     // current parameters
     __shared__ double mn[MAXNP];    // normalised current parameters
     __shared__ double test[MAXNP];  // proposal
@@ -625,6 +628,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     const long long t_begin = wall_clock64();
     const int nl = p.n_layers, NP = 2 * nl + 1, P = p.n_periods;
     LayerTable& T = g_T;
+    if (lane == 0) g_PS.prof_slot = ib;
 
     if (threadIdx.x < NP) {
         lo[threadIdx.x] = p.bounds[3 * threadIdx.x];

@@ -47,6 +47,7 @@ struct PredictScratch {
     unsigned short roff[MAXP + 1];  // number of abscissae of the pass before the period's
     int trouble;  // repairs the last predicted curve needed (9: the predictor gave up)
     int hinted;   // predict_hint for the last curve: 0 not tried, 1 settled, 2 gave up
+    int prof_slot;  // where a profiling build books this wave's cycles (the chain's index)
 };
 
 static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
@@ -67,7 +68,7 @@ __device__ unsigned long long g_prof[32];
 __device__ unsigned long long g_times[4096];
 __device__ unsigned long long g_blk[1024 * 8];
 #define PROF_T0 long long _t0 = clock64();
-#define PROF_ADD(i) { long long _t1 = clock64(); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_prof[i], (unsigned long long)(_t1 - _t0)); if (blockIdx.x < 1024) g_blk[blockIdx.x * 8 + i] += (unsigned long long)(_t1 - _t0); } _t0 = _t1; }
+#define PROF_ADD(i) { long long _t1 = clock64(); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_prof[i], (unsigned long long)(_t1 - _t0)); const int _ps = g_PS.prof_slot; if (_ps >= 0 && _ps < 1024) atomicAdd(&g_blk[_ps * 8 + i], (unsigned long long)(_t1 - _t0)); } _t0 = _t1; }
 #define HINT_WHY(i) if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[i], 1ull);
 #else
 #define PROF_T0
@@ -697,18 +698,53 @@ __device__ __forceinline__ int replay_period(int k, double& c1io, double clow, d
         c1 = c2;
     }
     if (!plain) return -1;
+    // The halvings.  This is a chain of dependent FP64 operations, which is what its time is made
+    // of, so the chain is kept short.  (1) The stopping test |c1 - c2| <= 1e-6 c1 cannot succeed
+    // while the ends are more than 2^-19 of the larger one apart (2^-19 > 1e-6): for that many
+    // halvings, counted from the binary exponents, it is left out, and with it the branch that
+    // waits for it.  (2) The next midpoint is computed for both outcomes of the current one
+    // while the current one is being compared with the root: with h = c / 2 for both ends,
+    // RN((c3 + c1) / 2) = fma(0.5, c3, h1) bit for bit (halving is exact, the sum is rounded
+    // once either way), so a halving costs one fma and one select in the chain.  The
+    // verification pass checks every abscissa and every side taken here against the plain
+    // 0.5 * (c1 + c2) arithmetic of replay_abscissa.
     unsigned long long bits = 0;
     int nh = 0;
-    double c3;
+    double c3 = 0.5 * (c1 + c2);
+    {
+        const int e_apart = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fabs(c1 - c2)));
+        const int e_ends = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fmax(c1, c2)));
+        // |c1 - c2| >= 2^(e_apart - 1), the ends stay below 2^e_ends: after n halvings the ends
+        // are at least 2^(e_apart - 1 - n - e_ends) of the larger one apart
+        int sure = e_apart - 1 - e_ends + 19;
+        sure = sure < 0 ? 0 : (sure > 38 ? 38 : sure);
+        double h1 = 0.5 * c1, h2 = 0.5 * c2;
+        for (int i = 0; i < sure; ++i) {
+            const bool left = (c3 <= lo) != below1;  // the sign at c3 differs from the one at c1
+            const double h3 = 0.5 * c3;
+            const double next_left = __builtin_fma(0.5, c3, h1);   // the ends become c1, c3
+            const double next_right = __builtin_fma(0.5, c3, h2);  // the ends become c3, c2
+            bits |= (unsigned long long)left << nh;
+            ++nh;
+            c2 = left ? c3 : c2;
+            h2 = left ? h3 : h2;
+            c1 = left ? c1 : c3;
+            h1 = left ? h1 : h3;
+            c3 = left ? next_left : next_right;
+        }
+    }
+    double last;
     for (;;) {
-        c3 = 0.5 * (c1 + c2);
-        const bool left = uni(c3 <= lo) != below1;  // the sign at c3 differs from the one at c1
+        const bool left = uni(c3 <= lo) != below1;
         bits |= (unsigned long long)left << nh;
         ++nh;
         if (left) c2 = c3; else c1 = c3;
+        last = c3;
         if (uni(fabs(c1 - c2) <= 1.0e-6 * c1)) break;
         if (nh >= 40) return -1;
+        c3 = 0.5 * (c1 + c2);
     }
+    c3 = last;
     // an abscissa inside the bracket would have become an end of [c1, c2]
     if (!uni(fmin(c1, c2) <= lo && fmax(c1, c2) >= hi)) return -1;
     if ((threadIdx.x & 63) == 0) {
@@ -842,10 +878,20 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
                 bool bad = false;
                 if (act) {
                     const int k = period_of(i);
-                    const double x = replay_abscissa(k, i - (int)S.roff[k], dc);
-                    const int want = (x <= S.lo[k]) ? (int)S.slo[k] : (int)S.shi[k];
+                    const int q = i - (int)S.roff[k];
+                    const double x = replay_abscissa(k, q, dc);
+                    const bool below = x <= S.lo[k];
+                    const int want = below ? (int)S.slo[k] : (int)S.shi[k];
                     const double omega = TWOPI / (t[k] / tscale);
                     bad = sgni(eval_secular(wave, omega, x).m) != want;
+                    // the replay's own arithmetic: the side it took at this halving, and the
+                    // answer it gave for the period
+                    const int meta = S.rmeta[k], ns = meta & 255, nh = (meta >> 8) & 255;
+                    if (q >= ns) {
+                        const bool took_left = (S.rbits[k] >> (q - ns)) & 1ull;
+                        bad = bad || took_left != (below != (S.rstart[k] <= S.lo[k]));
+                        if (q == ns + nh - 1 && k != kfail) bad = bad || x != c[k];
+                    }
                 }
                 const unsigned long long mask = __ballot(bad);
                 cnt.exec += (unsigned long long)__popcll(__ballot(act));
@@ -861,7 +907,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             for (int k = klit; k < kbad; ++k) cnt.lit += (int)S.roff[k + 1] - (int)S.roff[k];
             klit = kbad + 1;
 #ifdef MHD_PROFILE
-            if (lane == 0) { atomicAdd(&g_prof[6], 1ull); if (blockIdx.x < 1024) g_blk[blockIdx.x * 8 + 6] += 1; }
+            if (lane == 0) { atomicAdd(&g_prof[6], 1ull); const int _ps = g_PS.prof_slot; if (_ps >= 0 && _ps < 1024) atomicAdd(&g_blk[_ps * 8 + 6], 1ull); }
 #endif
             S.trouble = repairs + 1;
             if (++repairs > MAX_REPAIRS) {
