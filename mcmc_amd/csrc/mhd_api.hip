@@ -947,7 +947,13 @@ int mhd_debug_profile(unsigned long long* out16, int reset)
 {
     hipDeviceSynchronize();
     if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    if (reset) { unsigned long long z[48] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    return 0;
+}
+int mhd_debug_profile_hi2(unsigned long long* out16)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long), 32 * sizeof(unsigned long long));
     return 0;
 }
 int mhd_debug_profile_hi(unsigned long long* out16)

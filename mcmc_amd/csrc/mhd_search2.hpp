@@ -61,10 +61,25 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
 // twice the slope, is some tens per km/s; the replay wants 1e-12)
 #define ROOT_ERR_PRODUCT 2.0e-14
 
+// predict_coarse widens the windows it places by the hint: by HINT_STRETCH of the way along the
+// hint's curve since the last known root (the new model stretches or shrinks its steps), and by
+// HINT_TREND_SLACK of the trend carried on (a shift that changes fast is less certain)
+#ifndef HINT_STRETCH
+#define HINT_STRETCH 0.0
+#endif
+#ifndef HINT_TREND_SLACK
+#define HINT_TREND_SLACK 1.0
+#endif
+
+// share of the last period-to-period change of (root - hint) that predict_coarse carries on
+#ifndef HINT_TREND
+#define HINT_TREND 0.8
+#endif
+
 #pragma clang fp contract(off)
 
 #ifdef MHD_PROFILE
-__device__ unsigned long long g_prof[32];
+__device__ unsigned long long g_prof[48];
 __device__ unsigned long long g_times[4096];
 __device__ unsigned long long g_blk[1024 * 8];
 #define PROF_T0 long long _t0 = clock64();
@@ -103,9 +118,12 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
     double rprev = rprev_in, inc = 1.0, carry_base = 0.0;
     bool have_inc = false, carry = false;
     bool hint_ok = true;  // the next round may use the hint's shape
+    double trend = 0.0;   // change of (root - hint) from one period to the next, lately
+    double shift_prev = 0.0;
+    int shift_at = -2;    // the period shift_prev belongs to
     int hint_misses = 0;  // rounds in which it bracketed nothing
 #ifdef MHD_PROFILE
-    int prof_first = 0, prof_shaped = 0;
+    int prof_first = 0, prof_shaped = 0, prof_shaped_res = 0, prof_lat = 0, prof_lat_res = 0, prof_carry = 0, prof_down = 0;
 #endif
 
     while (k0 < P) {
@@ -115,16 +133,28 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
         int nq = 0, g = 1;
         const bool shaped = use_hint && hint_ok && k0 > 0 && !carry;
 #ifdef MHD_PROFILE
-        prof_first += (k0 == 0);
+        prof_first += (k0 == 0 && !carry);
         prof_shaped += shaped;
+        prof_carry += carry;
+        prof_lat += (!shaped && k0 > 0 && !carry);
 #endif
         if (shaped) {
             // around the expected root of each period, wider with the distance from the last
-            // known root: 5, 5, 7, 7, 9, 9, 11, 11 abscissae
+            // known root -- in periods (5, 5, 7, 7, ... abscissae) and along the hint's curve,
+            // whose steps the new model stretches or shrinks; as many periods as 64 lanes hold
+            // (the shift against the hint changes smoothly with the period: its last change is
+            // carried on, damped)
             int off = 0;
+            double path = 0.0;
             for (int q = 0; q < 8 && k0 + q < P; ++q) {
-                const double rq = rprev + (hint[k0 + q] - hint[k0 - 1]);
-                const int m = 2 + q / 2;
+                const double rq = rprev + (hint[k0 + q] - hint[k0 - 1]) + (q + 1) * trend;
+                path += fabs(hint[k0 + q] - hint[k0 + q - 1]);
+                int m = 2 + q / 2 + (int)((HINT_STRETCH * path + HINT_TREND_SLACK * (q + 1) * fabs(trend)) / dc);
+                m = m > 15 ? 15 : m;
+                if (off + 2 * m + 1 > 64) {
+                    if (q > 0) break;
+                    m = 31;
+                }
                 if (lane == 0) {
                     S.woff[q] = off;
                     S.wbase[q] = rq - (m + 0.5) * dc;
@@ -191,6 +221,13 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
                 const unsigned long long wm = (1ull << W) - 1ull;
                 const unsigned long long ng = (neg >> bit0) & wm, ps = (pos >> bit0) & wm;
                 const unsigned long long chg = ((ng << 1) & ps) | ((ps << 1) & ng);
+#ifdef MHD_PROFILE
+                if ((__popcll(chg) != 1 || __popcll(ng | ps) != W) && lane == 0) {
+                    atomicAdd(&g_prof[40 + (__popcll(chg) == 0 ? 0 : 1)], 1ull);
+                    atomicAdd(&g_prof[42], (unsigned long long)q);
+                    if (q < 2) atomicAdd(&g_prof[44 + (k < 10 ? 0 : (k < 20 ? 1 : (k < 30 ? 2 : 3)))], 1ull);
+                }
+#endif
                 if (__popcll(chg) != 1 || __popcll(ng | ps) != W) break;
                 const int j = (int)__ffsll((long long)chg) - 1;  // sign change between j-1 and j
                 const double sb = S.wbase[q];
@@ -203,6 +240,12 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
                 const double nr = sb + (j - 0.5) * dc;
                 inc = (nr - rprev) / dc;
                 have_inc = true;
+                if (use_hint) {
+                    const double sh = nr - hint[k];
+                    trend = (shift_at == k - 1) ? HINT_TREND * (sh - shift_prev) : 0.0;
+                    shift_prev = sh;
+                    shift_at = k;
+                }
                 rprev = nr;
                 ++resolved;
             }
@@ -240,6 +283,12 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
                         const double nr = s + (j2 + 0.5) * dc;
                         inc = (nr - rprev) / dc;
                         have_inc = true;
+                        if (use_hint) {
+                            const double sh = nr - hint[k];
+                            trend = (shift_at == k - 1) ? HINT_TREND * (sh - shift_prev) : 0.0;
+                            shift_prev = sh;
+                            shift_at = k;
+                        }
                         rprev = nr;
                         ++resolved;
                         continue;
@@ -275,6 +324,12 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
                     const double nr = st - (j3 - 0.5) * dc;
                     inc = (nr - rprev) / dc;
                     have_inc = true;
+                    if (use_hint) {
+                        const double sh = nr - hint[k];
+                        trend = (shift_at == k - 1) ? HINT_TREND * (sh - shift_prev) : 0.0;
+                        shift_prev = sh;
+                        shift_at = k;
+                    }
                     rprev = nr;
                     ++resolved;
                     break;
@@ -323,10 +378,19 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
                 inc = (nr - rprev) / dc;
                 have_inc = true;
             }
+            if (use_hint) {
+                const double sh = nr - hint[k];
+                trend = (shift_at == k - 1) ? HINT_TREND * (sh - shift_prev) : 0.0;
+                shift_prev = sh;
+                shift_at = k;
+            }
             rprev = nr;
             ++resolved;
             carry = false;
         }
+#ifdef MHD_PROFILE
+        if (shaped) prof_shaped_res += resolved; else if (k0 > 0) prof_lat_res += resolved;
+#endif
         k0 += resolved;
         if (resolved > 0 && !shaped && hint_misses < 4) hint_ok = true;
         if (resolved == 0 && !carried_now) {
@@ -344,6 +408,14 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
     if (lane == 0) {
         atomicAdd(&g_prof[14], (unsigned long long)rounds);
         atomicAdd(&g_prof[15], 1ull);
+        atomicAdd(&g_prof[32], (unsigned long long)prof_first);
+        atomicAdd(&g_prof[33], (unsigned long long)prof_shaped);
+        atomicAdd(&g_prof[34], (unsigned long long)prof_shaped_res);
+        atomicAdd(&g_prof[35], (unsigned long long)prof_lat);
+        atomicAdd(&g_prof[36], (unsigned long long)prof_lat_res);
+        atomicAdd(&g_prof[37], (unsigned long long)prof_carry);
+        atomicAdd(&g_prof[38], (unsigned long long)(use_hint ? 1 : 0));
+        atomicAdd(&g_prof[39], (unsigned long long)hint_misses);
     }
 #endif
     return P;
