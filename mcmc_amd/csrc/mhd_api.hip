@@ -175,11 +175,13 @@ __device__ __forceinline__ void hint_limit_update(float* limit, int kk, double c
 
 struct SearchPolicy {
     int level, left;
+    int max_level;  // 3, or 0 where the predictor has the chain's current curve to go by: there
+                    // repairing its curves costs less than the stepwise predictions do
     __device__ bool predicted() const { return level < 3; }
     __device__ int stepwise() const { return level == 0 ? 0 : (level == 1 ? 3 : 9); }
     __device__ void update(int forwards, bool trouble)
     {
-        if (level < 3 && trouble) {
+        if (level < max_level && trouble) {
             ++level;
             left = 8;
         } else if (level > 0) {
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     EvalCount cnt = {0, 0};
     // a chain whose curves keep defeating the predictor (densely spaced modes) uses the
     // wave-sequential search for a while, then tries the predictor again
-    SearchPolicy policy = {search == 2 ? 0 : 3, 0};
+    SearchPolicy policy = {search == 2 ? 0 : 3, 0, p.itype == MHD_PHASE ? 0 : 3};
     __syncthreads();
 
     for (int s = 0; s < S; ++s) {
@@ -422,7 +424,10 @@ constexpr int SCHED_MAX_CHAINS = 4096;  // one workgroup sorts them in LDS
 #ifndef SCHED_GAIN
 #define SCHED_GAIN 0.5f
 #endif
-constexpr int SCHED_SPARE = 8;           // workgroup places left free in a scheduled launch
+#ifndef SCHED_SPARE_N
+#define SCHED_SPARE_N 8
+#endif
+constexpr int SCHED_SPARE = SCHED_SPARE_N;           // workgroup places left free in a scheduled launch
 __device__ __constant__ float SCHED_CONSUMED[5] = {0.0f, 1.0f, 1.65f, 2.07f, 2.35f};
 
 struct SchedView {
@@ -655,11 +660,12 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     // how the curves of this chain are searched (see SearchPolicy); a chain goes on at the
     // level its last launch ended with
     const bool keeps = ch.sched && B <= SCHED_MAX_CHAINS;
-    SearchPolicy policy = {search == 2 ? 0 : 3, 0};
+    SearchPolicy policy = {search == 2 ? 0 : 3, 0, p.itype == MHD_PHASE ? 0 : 3};
     if (search == 2 && keeps) {
         // (NW = 4 serves the expensive chains, which mostly sit at level 1 or above; reading
         // the level there trips an instruction-selection bug of the compiler, so it is fixed)
-        const int lv = (NW == 4) ? 1 : ((int)sched_view(ch.sched, B).level[ib] & 3);
+        int lv = (NW == 4) ? 1 : ((int)sched_view(ch.sched, B).level[ib] & 3);
+        if (lv > policy.max_level) lv = policy.max_level;
         policy.level = lv;
         policy.left = lv > 0 ? 8 : 0;
     }
@@ -670,7 +676,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         // where this workgroup runs: HW_ID (register 4) and XCC_ID (register 20)
         const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
-        g_blk[ib * 8 + 5] = ((unsigned long long)xcc << 32) | hw | ((unsigned long long)NW << 60) | ((unsigned long long)split << 59);
+        (void)hw; (void)xcc;
     }
 #endif
     group_sync();
@@ -744,6 +750,12 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         deadline = (unsigned long long)(unsigned)sv.n4[2] | ((unsigned long long)(unsigned)sv.n4[3] << 32);
     }
     const int s_begin = s;
+#ifdef MHD_PROFILE
+    // where the chain's last launch of the call started: step, candidates
+    if (writer && lane == 0 && ib < 1024 && s < S && s > 0)
+        g_blk[ib * 8 + 5] = ((unsigned long long)s << 32) | (unsigned long long)nw;
+    if (writer && lane == 0 && ib < 1024 && s == 0) g_times[2 * (1024 + ib)] = (unsigned long long)wall_clock64();
+#endif
     while (s < S) {
         // ---- this wave's candidate: the (w-w0+1)-th proposal from step s on that passes the
         // bounds
@@ -838,6 +850,13 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
 
 #ifdef MHD_PROFILE
     if (writer && lane == 0 && ib < 2048) g_times[2 * ib + 1] = (unsigned long long)wall_clock64();
+#endif
+#ifdef MHD_PROFILE
+    // the call's first launch: steps done, ticks taken, waves per workgroup, split, candidates
+    if (writer && lane == 0 && ib < 1024 && s_begin == 0)
+        g_times[2 * (1024 + ib) + 1] = ((unsigned long long)s << 48) |
+                                       (((unsigned long long)(wall_clock64() - t_begin) & 0xFFFFFFFFull) << 12) |
+                                       ((unsigned long long)NW << 4) | ((unsigned long long)split << 3) | (unsigned long long)nw;
 #endif
     if (writer && lane == 0 && keeps) {
         if (search == 2) sched_view(ch.sched, B).level[ib] = (unsigned char)policy.level;
@@ -948,6 +967,12 @@ int mhd_debug_profile(unsigned long long* out16, int reset)
     hipDeviceSynchronize();
     if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long));
     if (reset) { unsigned long long z[48] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    return 0;
+}
+int mhd_debug_chain(unsigned int* out16384)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16384, HIP_SYMBOL(g_chain), 16384 * sizeof(unsigned int));
     return 0;
 }
 int mhd_debug_profile_hi2(unsigned long long* out16)

@@ -82,12 +82,15 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
 __device__ unsigned long long g_prof[48];
 __device__ unsigned long long g_times[4096];
 __device__ unsigned long long g_blk[1024 * 8];
+__device__ unsigned int g_chain[1024 * 16];  // event counts per chain, see CHAIN_EVENT
+#define CHAIN_EVENT(i) { const int _pc = g_PS.prof_slot; if ((threadIdx.x & 63) == 0 && _pc >= 0 && _pc < 1024) atomicAdd(&g_chain[_pc * 16 + (i)], 1u); }
 #define PROF_T0 long long _t0 = clock64();
 #define PROF_ADD(i) { long long _t1 = clock64(); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_prof[i], (unsigned long long)(_t1 - _t0)); const int _ps = g_PS.prof_slot; if (_ps >= 0 && _ps < 1024) atomicAdd(&g_blk[_ps * 8 + i], (unsigned long long)(_t1 - _t0)); } _t0 = _t1; }
 #define HINT_WHY(i) if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[i], 1ull);
 #else
 #define PROF_T0
 #define PROF_ADD(i)
+#define CHAIN_EVENT(i) {}
 #define HINT_WHY(i)
 #endif
 
@@ -872,9 +875,13 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
     PROF_T0
     int nP = -1;
     S.hinted = 0;
+    CHAIN_EVENT(0)
+    if (stepwise) CHAIN_EVENT(9)
     if (!stepwise && use_hint == 2) {
         nP = predict_hint(wave, t, P, tscale, dc, hint, cnt);
         S.hinted = nP < 0 ? 2 : 1;
+        CHAIN_EVENT(1)
+        if (nP < 0) CHAIN_EVENT(2)
         PROF_ADD(0)
 #ifdef MHD_PROFILE
         if (lane == 0) { atomicAdd(&g_prof[11], 1ull); atomicAdd(&g_prof[12], (unsigned long long)(nP < 0)); }
@@ -916,6 +923,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             const int r = replay_period(k, c1, clow, dc, cm, betmx + dc, betmx, ifirst, s1st, count);
             if (r < 0) {
                 kplain = k;
+                CHAIN_EVENT(7)
                 break;
             }
             if (lane == 0) S.roff[k] = (unsigned short)npts;
@@ -982,7 +990,9 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             if (lane == 0) { atomicAdd(&g_prof[6], 1ull); const int _ps = g_PS.prof_slot; if (_ps >= 0 && _ps < 1024) atomicAdd(&g_blk[_ps * 8 + 6], 1ull); }
 #endif
             S.trouble = repairs + 1;
+            CHAIN_EVENT(4)
             if (++repairs > MAX_REPAIRS) {
+                CHAIN_EVENT(10)
                 const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kbad, s1st);
                 PROF_ADD(4)
 #ifdef MHD_PROFILE
@@ -1002,6 +1012,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             wave_sync();
             if (kbad + 1 >= P) return MHD_ST_OK;
             if (uni(cr == cold)) {
+                CHAIN_EVENT(8)
                 // same answer: the replay of the later periods stands; verify on from the
                 // first abscissa of the next period
                 vbeg = (int)S.roff[kbad + 1];
@@ -1011,9 +1022,11 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             again = true;
             const double plo = uniform_value(S.lo[kbad]), phi = uniform_value(S.hi[kbad]);
             if (kbad < nP - 1 && uni(cr >= plo - 2.0e-6 * cr && cr <= phi + 2.0e-6 * cr)) {
+                CHAIN_EVENT(6)
                 // same root on another lattice: the predictions for the later periods stand
                 break;
             }
+            CHAIN_EVENT(5)
             // the sequential search moved to another branch than the predictor's: predict the
             // remaining periods again, continuing from the root it found
             nP = stepwise ? predict_stepwise(wave, t, kstart, P, tscale, dc, cr, s1st, stepwise, cnt)

@@ -43,7 +43,20 @@ ph1 = st > 1000
 print("second launch: chains %d, starts at us %.0f; their finish us p50 %.0f p90 %.0f p99 %.0f max %.0f | first-launch-only chains finish p50 %.0f max %.0f" % (ph1.sum(), st[ph1].min() if ph1.any() else 0, *np.percentile(en[ph1], [50, 90, 99, 100]), np.median(en[~ph1]), en[~ph1].max()))
 print("makespan us %.0f" % en.max())
 late = np.argsort(en)[-8:]
-print("latest finishers (chain, cost us, finish us):", [(int(i), int(cost[i]/100), int(en[i])) for i in late])
+lib.mhd_debug_blk(bb0 := (ctypes.c_ulonglong*8192)(), 0)
+r5 = np.array(list(bb0), dtype=np.uint64).reshape(1024, 8)[:, 5]
+r4 = np.array(list(tt),dtype=np.float64).reshape(2048,2)[1024:, 0]
+st0 = (r4 - r4.min()) / 100.0
+print("first launch: chains starting later than 1 ms: %d; their starts us: %s" % ((st0 > 1000).sum(), sorted(int(v) for v in st0[st0 > 1000])))
+p0 = np.array(list(tt),dtype=np.uint64).reshape(2048,2)[1024:, 1]
+p0_steps = (p0 >> np.uint64(48)).astype(np.int64); p0_us = ((p0 >> np.uint64(12)) & np.uint64(0xFFFFFFFF)).astype(np.float64)/100; p0_nw = (p0 & np.uint64(7)).astype(np.int64); p0_NW = ((p0 >> np.uint64(4)) & np.uint64(15)).astype(np.int64)
+print("first launch by class: ", [(j, int((p0_nw==j).sum()), "steps p10/p50/p90 %d %d %d" % tuple(np.percentile(p0_steps[p0_nw==j],[10,50,90])), "us %.0f" % np.median(p0_us[p0_nw==j])) for j in (1,2,4) if (p0_nw==j).any()])
+slowp0 = np.argsort(p0_steps)[:12]
+print("fewest steps in the first launch (chain, steps, us, candidates, cost us):", [(int(i), int(p0_steps[i]), int(p0_us[i]), int(p0_nw[i]), int(cost[i]/100)) for i in slowp0])
+sb = (r5 >> np.uint64(32)).astype(np.int64); jw = (r5 & np.uint64(0xFF)).astype(np.int64)
+print("latest finishers (chain, cost us, step at which its last launch began, candidates there, start us, finish us, us per step there):", [(int(i), int(cost[i]/100), int(sb[i]), int(jw[i]), int(st[i]), int(en[i]), int((en[i]-st[i])/max(250-sb[i],1))) for i in late])
+m1 = ph1
+print("second launch: us per step by candidates: J2 median %.0f, J4 median %.0f | steps left at its start: p10 %.0f p50 %.0f p90 %.0f max %.0f" % (np.median(((en-st)/np.maximum(250-sb,1))[m1 & (jw==2)]), np.median(((en-st)/np.maximum(250-sb,1))[m1 & (jw==4)]), *np.percentile((250-sb)[m1], [10,50,90,100])))
 bb=(ctypes.c_ulonglong*8192)()
 lib.mhd_debug_blk(bb,0)
 raw5=np.array(list(bb),dtype=np.uint64).reshape(1024,8)[:,5]
@@ -60,3 +73,15 @@ print("median chains:")
 for i in np.argsort(-cost)[510:514]:
     tot = cnt_[i, 0] + cnt_[i, 1]
     print("  %4d %5.0f J%d fw/step %.2f | %s | mism %.2f | acc %.3f bounds %.3f" % (i, cost[i] / 100, 0, fw[i] / 750, " ".join("%4.0f" % (c / max(fw[i], 1) / 1000) for c in cyc[i]), mism[i] / max(fw[i], 1), cnt_[i, 0] / tot, cnt_[i, 2] / tot))
+
+gc = (ctypes.c_uint * 16384)(); lib.mhd_debug_chain(gc)
+ev = np.array(list(gc), dtype=np.float64).reshape(1024, 16)
+names = ["curves", "hint tried", "hint gave up", "-", "repairs", "predicted again", "same root", "not plain", "same answer", "stepwise", "finished sequentially"]
+def show(i):
+    n = max(ev[i, 0], 1)
+    return "chain %4d cost %4.0f | curves %5d | per curve: " % (i, cost[i] / 100, ev[i, 0]) + ", ".join("%s %.2f" % (names[j], ev[i, j] / n) for j in (1, 2, 9, 4, 8, 6, 5, 7, 10))
+print("events of the most expensive chains:")
+for i in np.argsort(-cost)[:8]: print("  " + show(i))
+print("of median chains:")
+for i in np.argsort(-cost)[510:514]: print("  " + show(i))
+tot = ev.sum(0); print("all chains per curve: " + ", ".join("%s %.3f" % (names[j], tot[j] / tot[0]) for j in (1, 2, 9, 4, 8, 6, 5, 7, 10)))
