@@ -30,6 +30,8 @@
 namespace mhd {
 
 constexpr int MAX_REPAIRS = 3;  // then the wave-sequential search finishes the curve
+constexpr int MAX_SCAN = 62;    // scan abscissae of one period the replay follows; longer scans are mostly
+                                // downward ones that end at the floor, which the wave-sequential search handles
 
 struct PredictScratch {
     double lo[MAXP], hi[MAXP];    // root bracket per period (stage 1: one dc cell)
@@ -748,8 +750,10 @@ __device__ __forceinline__ int replay_period(int k, double& c1io, double clow, d
     const double lo = uniform_value(S.lo[k]), hi = uniform_value(S.hi[k]);
     const int slo = __builtin_amdgcn_readfirstlane((int)S.slo[k]);
     const int shi = __builtin_amdgcn_readfirstlane((int)S.shi[k]);
-    if (slo == 0 || shi == 0) return -1;
-    if (slo == shi) return -1;
+    if (slo == 0 || shi == 0 || slo == shi) {
+        CHAIN_EVENT(11)
+        return -1;
+    }
     // slo != shi: the inferred sign of an abscissa is known by its side of the bracket alone
     // (below: x <= lo).  The side is uniform; kept as a scalar, it costs no vector compare of
     // signs, and the side of c1 cannot change during the halvings.
@@ -765,14 +769,20 @@ __device__ __forceinline__ int replay_period(int k, double& c1io, double clow, d
         c2 = c1 + step;
         ++ns;
         const bool below2 = uni(c2 <= lo);
-        plain = uni(c2 > clow) && (ns <= 62);
+        plain = uni(c2 > clow) && (ns <= MAX_SCAN);
         if (below1 != below2 || !plain || uni(c2 < cm || c2 >= top)) {
             plain = plain && (below1 != below2);
             break;
         }
         c1 = c2;
     }
-    if (!plain) return -1;
+    if (!plain) {
+        if (ns > MAX_SCAN) CHAIN_EVENT(12)
+        else if (!uni(c2 > clow)) CHAIN_EVENT(13)
+        else CHAIN_EVENT(14)
+        if (ifirst) CHAIN_EVENT(3)
+        return -1;
+    }
     // The halvings.  This is a chain of dependent FP64 operations, which is what its time is made
     // of, so the chain is kept short.  (1) The stopping test |c1 - c2| <= 1e-6 c1 cannot succeed
     // while the ends are more than 2^-19 of the larger one apart (2^-19 > 1e-6): for that many
@@ -821,7 +831,10 @@ __device__ __forceinline__ int replay_period(int k, double& c1io, double clow, d
     }
     c3 = last;
     // an abscissa inside the bracket would have become an end of [c1, c2]
-    if (!uni(fmin(c1, c2) <= lo && fmax(c1, c2) >= hi)) return -1;
+    if (!uni(fmin(c1, c2) <= lo && fmax(c1, c2) >= hi)) {
+        CHAIN_EVENT(15)
+        return -1;
+    }
     if ((threadIdx.x & 63) == 0) {
         S.rstart[k] = start;
         S.rbits[k] = bits;

@@ -84,4 +84,5 @@ print("events of the most expensive chains:")
 for i in np.argsort(-cost)[:8]: print("  " + show(i))
 print("of median chains:")
 for i in np.argsort(-cost)[510:514]: print("  " + show(i))
-tot = ev.sum(0); print("all chains per curve: " + ", ".join("%s %.3f" % (names[j], tot[j] / tot[0]) for j in (1, 2, 9, 4, 8, 6, 5, 7, 10)))
+tot = ev.sum(0); print("not plain, per curve: no bracket %.3f, more than 62 scan steps %.3f, scan reaches the floor %.3f, scan ends without a change %.3f, root outside the final ends %.3f; in the first period %.3f" % tuple(tot[j]/tot[0] for j in (11,12,13,14,15,3)))
+print("all chains per curve: " + ", ".join("%s %.3f" % (names[j], tot[j] / tot[0]) for j in (1, 2, 9, 4, 8, 6, 5, 7, 10)))
