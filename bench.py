@@ -105,6 +105,21 @@ def cpu_baseline(periods, bounds, obs, starts, seed, budget_s=12.0):
     }
 
 
+def measured_traffic(headline, args):
+    """HBM-side bytes per call of the library (TCC FETCH_SIZE + WRITE_SIZE of all its kernels), taken
+    from the committed rocprofv3 --pmc summary of this same command; None for any other
+    configuration, or when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r1_v5_traffic.json")
+    if not (headline and args.chunk == 250 and args.search == 2 and args.candidates == 2):
+        return None
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return (d["fetch_kb_per_call"] + d["write_kb_per_call"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,8 +251,10 @@ def main():
                 "peak": FP64_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-                "traffic": None,
-                "kernel": "mh_steps_multi_kernel" + ("<2> (with <4> beside it)" if args.candidates == 2
+                "traffic": measured_traffic(headline, args),
+                "kernel": "mh_steps_multi_kernel" + ("<2> (with <4> beside it; a call of the library "
+                                                   "launches both twice, and launch_ms is the call)"
+                                                   if args.candidates == 2
                                                    else "<%d>" % args.candidates),
                 "launch_ms": launch_s * 1e3,
                 "algorithmic_evals_per_launch": lit / n_launch,
