@@ -103,11 +103,13 @@ typedef struct mhd_chains {
     const double *beta;  /* device [B] tempering exponent, or NULL for 1      */
     void *sched;         /* device, mhd_sched_bytes(B) bytes, or NULL: scratch the
                             library keeps between calls of mhd_mh_steps (what each
-                            chain's steps cost last time); zero it once, before the
-                            first call.  With it, the chains that take longest get
-                            four candidates in flight instead of two and the chains
-                            are started longest first.  Results do not depend on it;
-                            no counterpart in the reference                       */
+                            chain's steps cost last time) and within one (how far
+                            each chain has got); zero it once, before the first
+                            call.  With it a call is two launches: the first ends
+                            at a deadline, the second gives the chains that are
+                            behind more candidates in flight; the chains that take
+                            longest get four candidates from the start.  Results
+                            do not depend on it; no counterpart in the reference */
 } mhd_chains_t;
 
 /* Size of mhd_chains_t.sched for B chains. */
