@@ -969,10 +969,10 @@ int mhd_debug_profile(unsigned long long* out16, int reset)
     if (reset) { unsigned long long z[48] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
     return 0;
 }
-int mhd_debug_chain(unsigned int* out16384)
+int mhd_debug_chain(unsigned int* out32768)
 {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out16384, HIP_SYMBOL(g_chain), 16384 * sizeof(unsigned int));
+    hipMemcpyFromSymbol(out32768, HIP_SYMBOL(g_chain), 32768 * sizeof(unsigned int));
     return 0;
 }
 int mhd_debug_profile_hi2(unsigned long long* out16)

@@ -84,8 +84,8 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
 __device__ unsigned long long g_prof[48];
 __device__ unsigned long long g_times[4096];
 __device__ unsigned long long g_blk[1024 * 8];
-__device__ unsigned int g_chain[1024 * 16];  // event counts per chain, see CHAIN_EVENT
-#define CHAIN_EVENT(i) { const int _pc = g_PS.prof_slot; if ((threadIdx.x & 63) == 0 && _pc >= 0 && _pc < 1024) atomicAdd(&g_chain[_pc * 16 + (i)], 1u); }
+__device__ unsigned int g_chain[1024 * 32];  // event counts per chain, see CHAIN_EVENT
+#define CHAIN_EVENT(i) { const int _pc = g_PS.prof_slot; if ((threadIdx.x & 63) == 0 && _pc >= 0 && _pc < 1024) atomicAdd(&g_chain[_pc * 32 + (i)], 1u); }
 #define PROF_T0 long long _t0 = clock64();
 #define PROF_ADD(i) { long long _t1 = clock64(); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_prof[i], (unsigned long long)(_t1 - _t0)); const int _ps = g_PS.prof_slot; if (_ps >= 0 && _ps < 1024) atomicAdd(&g_blk[_ps * 8 + i], (unsigned long long)(_t1 - _t0)); } _t0 = _t1; }
 #define HINT_WHY(i) if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[i], 1ull);
@@ -235,6 +235,12 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
 #endif
                 if (__popcll(chg) != 1 || __popcll(ng | ps) != W) break;
                 const int j = (int)__ffsll((long long)chg) - 1;  // sign change between j-1 and j
+                // The sequential scan goes upward only if the sign at its start is the one below
+                // the first root of the first period; a root with the other sign below it is one
+                // the scan will not arrive at from below (it turns downward at its start): the
+                // next round looks at this period from its scan start.
+                if (sigma0 != 0 && (int)((ps >> (j - 1)) & 1ull) - (int)((ng >> (j - 1)) & 1ull) != sigma0)
+                    break;
                 const double sb = S.wbase[q];
                 S.lo[k] = sb + (j - 1) * dc;
                 S.fam[k] = (float)S.fm[bit0 + j - 1];
@@ -614,6 +620,7 @@ __device__ MHD_NOINLINE int predict_hint(int wave, const double* t, int P, doubl
     PredictScratch& S = g_PS;
     const int lane = threadIdx.x & 63;
     const double cc = g_T.cc, top = g_T.betmx + dc;
+    int first_slo = 0;
     for (int kb = 0; kb < P; kb += 64) {
         const int k = kb + lane;
         const bool active = k < P;
@@ -720,10 +727,17 @@ __device__ MHD_NOINLINE int predict_hint(int wave, const double* t, int P, doubl
                 e1 = v.e;
             }
         }
+        // never bracketed: every iterate lies on one side of the root
+        const int s1 = sgni(f1);
+        const int slo = bracketed ? sa : (root > x1 ? s1 : -s1);
+        // every root must have the sign below it that the first period's has: the sequential scan
+        // does not arrive from below at a root with the other one (see predict_coarse)
+        if (kb == 0) first_slo = __builtin_amdgcn_readfirstlane(slo);
+        if (__ballot(active && slo != first_slo) != 0ull) {
+            HINT_WHY(16)
+            return -1;
+        }
         if (active) {
-            // never bracketed: every iterate lies on one side of the root
-            const int s1 = sgni(f1);
-            const int slo = bracketed ? sa : (root > x1 ? s1 : -s1);
             S.lo[k] = root;
             S.hi[k] = root;
             S.slo[k] = (signed char)slo;
@@ -1021,6 +1035,24 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
                                               cm, betmx, ifirst, s1st, cnt);
             PROF_ADD(4)
             if (!ok) return MHD_ST_NOROOT;
+#ifdef MHD_PROFILE
+            {
+                // where the sequential search ended against the predicted root, and where in the
+                // period the first wrong sign was
+                const double pr = uniform_value(S.lo[kbad]);
+                if (uni(cr > pr + 0.5 * dc)) CHAIN_EVENT(16)
+                else if (uni(cr < pr - 0.5 * dc)) CHAIN_EVENT(17)
+                else CHAIN_EVENT(18)
+                const int qbad = first_bad - (int)S.roff[kbad];
+                if (qbad < (S.rmeta[kbad] & 255)) CHAIN_EVENT(19)
+                else CHAIN_EVENT(20)
+                if (uni(cr > pr + 8.0 * dc)) CHAIN_EVENT(21)
+                if (kbad >= 30) CHAIN_EVENT(22)
+                else if (kbad >= 20) CHAIN_EVENT(23)
+                else if (kbad >= 10) CHAIN_EVENT(24)
+                else CHAIN_EVENT(25)
+            }
+#endif
             c[kbad] = cr;
             wave_sync();
             if (kbad + 1 >= P) return MHD_ST_OK;
