@@ -30,6 +30,9 @@
 namespace mhd {
 
 constexpr int MAX_REPAIRS = 3;  // then the wave-sequential search finishes the curve
+#ifndef RESYNC_PERIODS
+#define RESYNC_PERIODS 2
+#endif
 constexpr int MAX_SCAN = 62;    // scan abscissae of one period the replay follows; longer scans are mostly
                                 // downward ones that end at the floor, which the wave-sequential search handles
 
@@ -1053,6 +1056,15 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
                 else CHAIN_EVENT(25)
             }
 #endif
+#ifdef MHD_DEBUG_REPAIR
+            if (lane == 0) {
+                const int qb = first_bad - (int)S.roff[kbad];
+                printf("repair k %d hinted %d | scan start %.6f predicted root %.6f (slo %d) found %.6f | prev c %.6f | hint k-1 %.6f k %.6f | wrong sign at abscissa %d of %d scan + %d halvings, x %.6f | roots k-2..k+2: %.5f %.5f %.5f %.5f %.5f\n",
+                       kbad, S.hinted, (kbad ? c[kbad - 1] - 1.5 * dc : cc), S.lo[kbad], (int)S.slo[kbad], cr, kbad ? c[kbad - 1] : 0.0,
+                       use_hint && kbad ? hint[kbad - 1] : 0.0, use_hint ? hint[kbad] : 0.0, qb, S.rmeta[kbad] & 255, (S.rmeta[kbad] >> 8) & 255,
+                       replay_abscissa(kbad, qb, dc), kbad > 1 ? S.lo[kbad - 2] : 0.0, kbad ? S.lo[kbad - 1] : 0.0, S.lo[kbad], kbad + 1 < nP ? S.lo[kbad + 1] : 0.0, kbad + 2 < nP ? S.lo[kbad + 2] : 0.0);
+            }
+#endif
             c[kbad] = cr;
             wave_sync();
             if (kbad + 1 >= P) return MHD_ST_OK;
@@ -1070,6 +1082,32 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
                 CHAIN_EVENT(6)
                 // same root on another lattice: the predictions for the later periods stand
                 break;
+            }
+            // The sequential search is on another branch than the predictor's here.  In the models
+            // where that happens (a slow branch that ends, the next one above it) the two mostly
+            // differ in the period at which the search changes over, by one or two periods: the
+            // next periods are searched sequentially while that lasts, and once an answer is the
+            // predicted root again the predictions for the later periods stand.
+            {
+                bool resynced = false;
+                for (int tries = 0; tries < RESYNC_PERIODS && kstart < nP && !resynced; ++tries) {
+                    const int k = kstart;
+                    double ck = uniform_value(c[k - 1]) - 1.5 * dc;
+                    const bool ok2 = solve_period_wave(T, wave, t[k] / tscale, ck, cm, dc, cm, betmx,
+                                                       false, s1st, cnt);
+                    PROF_ADD(4)
+                    if (!ok2) return MHD_ST_NOROOT;
+                    c[k] = ck;
+                    wave_sync();
+                    kstart = k + 1;
+                    if (kstart >= P) return MHD_ST_OK;
+                    resynced = uni(fabs(ck - uniform_value(S.lo[k])) <= 2.0e-6 * ck);
+                    cr = ck;
+                }
+                if (resynced && kstart < nP) {
+                    CHAIN_EVENT(26)
+                    break;
+                }
             }
             CHAIN_EVENT(5)
             // the sequential search moved to another branch than the predictor's: predict the

@@ -76,16 +76,16 @@ for i in np.argsort(-cost)[510:514]:
 
 gc = (ctypes.c_uint * 32768)(); lib.mhd_debug_chain(gc)
 ev = np.array(list(gc), dtype=np.float64).reshape(1024, 32)
-names = ["curves", "hint tried", "hint gave up", "-", "repairs", "predicted again", "same root", "not plain", "same answer", "stepwise", "finished sequentially"]
+names = ["curves", "hint tried", "hint gave up", "-", "repairs", "predicted again", "same root", "not plain", "same answer", "stepwise", "finished sequentially"] + ["-"]*15 + ["resynchronised"]
 def show(i):
     n = max(ev[i, 0], 1)
-    return "chain %4d cost %4.0f | curves %5d | per curve: " % (i, cost[i] / 100, ev[i, 0]) + ", ".join("%s %.2f" % (names[j], ev[i, j] / n) for j in (1, 2, 9, 4, 8, 6, 5, 7, 10))
+    return "chain %4d cost %4.0f | curves %5d | per curve: " % (i, cost[i] / 100, ev[i, 0]) + ", ".join("%s %.2f" % (names[j], ev[i, j] / n) for j in (1, 2, 9, 4, 8, 6, 26, 5, 7, 10))
 print("events of the most expensive chains:")
 for i in np.argsort(-cost)[:8]: print("  " + show(i))
 print("of median chains:")
 for i in np.argsort(-cost)[510:514]: print("  " + show(i))
 tot = ev.sum(0); print("not plain, per curve: no bracket %.3f, more than 62 scan steps %.3f, scan reaches the floor %.3f, scan ends without a change %.3f, root outside the final ends %.3f; in the first period %.3f" % tuple(tot[j]/tot[0] for j in (11,12,13,14,15,3)))
-print("all chains per curve: " + ", ".join("%s %.3f" % (names[j], tot[j] / tot[0]) for j in (1, 2, 9, 4, 8, 6, 5, 7, 10)))
+print("all chains per curve: " + ", ".join("%s %.3f" % (names[j], tot[j] / tot[0]) for j in (1, 2, 9, 4, 8, 6, 26, 5, 7, 10)))
 
 rp = max(tot[4], 1)
 print("repairs: sequential search ended above the predicted root %.3f (more than 8 dc above %.3f), below %.3f, near %.3f | first wrong sign in the scan %.3f, in the halvings %.3f | period >=30 %.3f, 20-29 %.3f, 10-19 %.3f, <10 %.3f" % tuple(tot[j] / rp for j in (16, 21, 17, 18, 19, 20, 22, 23, 24, 25)))
