@@ -31,7 +31,7 @@ namespace mhd {
 
 constexpr int MAX_REPAIRS = 3;  // then the wave-sequential search finishes the curve
 #ifndef RESYNC_PERIODS
-#define RESYNC_PERIODS 2
+#define RESYNC_PERIODS 4
 #endif
 constexpr int MAX_SCAN = 62;    // scan abscissae of one period the replay follows; longer scans are mostly
                                 // downward ones that end at the floor, which the wave-sequential search handles
