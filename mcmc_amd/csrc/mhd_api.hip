@@ -425,7 +425,7 @@ constexpr int SCHED_MAX_CHAINS = 4096;  // one workgroup sorts them in LDS
 #define SCHED_GAIN 0.5f
 #endif
 #ifndef SCHED_SPARE_N
-#define SCHED_SPARE_N 8
+#define SCHED_SPARE_N 64
 #endif
 constexpr int SCHED_SPARE = SCHED_SPARE_N;           // workgroup places left free in a scheduled launch
 __device__ __constant__ float SCHED_CONSUMED[5] = {0.0f, 1.0f, 1.65f, 2.07f, 2.35f};
@@ -470,7 +470,7 @@ constexpr int SCHED_PHASES = SCHED_PHASES_N;
 #define PHASE_DEADLINE_LATER 1.0f  // later deadlines, in units of the median unfinished chain's
 #endif
 #ifndef PHASE_DEADLINE_FRACTION
-#define PHASE_DEADLINE_FRACTION 0.9f  // first deadline, in units of the median chain's expected time
+#define PHASE_DEADLINE_FRACTION 0.8f  // first deadline, in units of the median chain's expected time
 #endif
 
 __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S, int phase,
