@@ -44,6 +44,7 @@ struct PredictScratch {
     double fm[64];  // lane values of the current stage-1 round
     int fe[64];
     double wbase[8];  // windows of the current stage-1 round: first abscissa ...
+    double wstep[8];  // ... spacing ...
     int woff[9];      // ... and first lane
     // what the replay did for each period (see replay_period)
     double rstart[MAXP];
@@ -65,6 +66,14 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
 // bound on the product it is taken as the root without being evaluated (C, the curvature over
 // twice the slope, is some tens per km/s; the replay wants 1e-12)
 #define ROOT_ERR_PRODUCT 2.0e-14
+
+// hint steps (in dc) from which predict_coarse spaces the abscissae of a window 2 and 4 dc apart
+#ifndef WIDE_STEP_2
+#define WIDE_STEP_2 3.0
+#endif
+#ifndef WIDE_STEP_4
+#define WIDE_STEP_4 8.0
+#endif
 
 // predict_coarse widens the windows it places by the hint: by HINT_STRETCH of the way along the
 // hint's curve since the last known root (the new model stretches or shrinks its steps), and by
@@ -152,12 +161,17 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
             // whose steps the new model stretches or shrinks; as many periods as 64 lanes hold
             // (the shift against the hint changes smoothly with the period: its last change is
             // carried on, damped)
+            // Where the hint's curve is steep (long periods) the new model's steps differ from
+            // the hint's by several dc: there the abscissae of a window are 2 or 4 dc apart
+            // (the refinement starts from a bracket of that width just as well).
             int off = 0;
             double path = 0.0;
             for (int q = 0; q < 8 && k0 + q < P; ++q) {
                 const double rq = rprev + (hint[k0 + q] - hint[k0 - 1]) + (q + 1) * trend;
-                path += fabs(hint[k0 + q] - hint[k0 + q - 1]);
-                int m = 2 + q / 2 + (int)((HINT_STRETCH * path + HINT_TREND_SLACK * (q + 1) * fabs(trend)) / dc);
+                const double hstep = fabs(hint[k0 + q] - hint[k0 + q - 1]);
+                path += hstep;
+                const double gs = (hstep < WIDE_STEP_2 * dc ? 1.0 : (hstep < WIDE_STEP_4 * dc ? 2.0 : 4.0)) * dc;
+                int m = 2 + q / 2 + (int)((HINT_STRETCH * path + HINT_TREND_SLACK * (q + 1) * fabs(trend)) / gs);
                 m = m > 15 ? 15 : m;
                 if (off + 2 * m + 1 > 64) {
                     if (q > 0) break;
@@ -165,7 +179,8 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
                 }
                 if (lane == 0) {
                     S.woff[q] = off;
-                    S.wbase[q] = rq - (m + 0.5) * dc;
+                    S.wbase[q] = rq - (m + 0.5) * gs;
+                    S.wstep[q] = gs;
                 }
                 off += 2 * m + 1;
                 nq = q + 1;
@@ -196,6 +211,7 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
                     }
                     S.woff[q] = q * W;
                     S.wbase[q] = b;
+                    S.wstep[q] = dc;
                 }
                 S.woff[nq] = nq * W;
             }
@@ -208,7 +224,7 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
         SecVal v = {0.0, 0};
         if (active) {
             const double omega = TWOPI / (t[k0 + jj] / tscale);
-            v = eval_secular(wave, omega, S.wbase[jj] + (lane - S.woff[jj]) * dc);
+            v = eval_secular(wave, omega, S.wbase[jj] + (lane - S.woff[jj]) * S.wstep[jj]);
         }
         const unsigned long long neg = __ballot(active && v.m < 0.0);
         const unsigned long long pos = __ballot(active && v.m > 0.0);
@@ -222,8 +238,8 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
         int resolved = 0;
         bool carried_now = false;
         if (shaped) {
-            // a period is bracketed when its window holds exactly one sign change (whether the
-            // sequential scan meets another one before it is for the verification to find out)
+            // a period is bracketed when its window holds a sign change (whether the sequential
+            // scan meets another one before it is for the verification to find out)
             for (int q = 0; q < nq; ++q) {
                 const int k = k0 + q, bit0 = S.woff[q], W = S.woff[q + 1] - bit0;
                 const unsigned long long wm = (1ull << W) - 1ull;
@@ -236,7 +252,8 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
                     if (q < 2) atomicAdd(&g_prof[44 + (k < 10 ? 0 : (k < 20 ? 1 : (k < 30 ? 2 : 3)))], 1ull);
                 }
 #endif
-                if (__popcll(chg) != 1 || __popcll(ng | ps) != W) break;
+                if (chg == 0ull || __popcll(ng | ps) != W) break;
+                // (of several sign changes the lowest: the scan comes from below)
                 const int j = (int)__ffsll((long long)chg) - 1;  // sign change between j-1 and j
                 // The sequential scan goes upward only if the sign at its start is the one below
                 // the first root of the first period; a root with the other sign below it is one
@@ -244,14 +261,20 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
                 // next round looks at this period from its scan start.
                 if (sigma0 != 0 && (int)((ps >> (j - 1)) & 1ull) - (int)((ng >> (j - 1)) & 1ull) != sigma0)
                     break;
-                const double sb = S.wbase[q];
-                S.lo[k] = sb + (j - 1) * dc;
+                const double sb = S.wbase[q], gs = S.wstep[q];
+                S.lo[k] = sb + (j - 1) * gs;
                 S.fam[k] = (float)S.fm[bit0 + j - 1];
                 S.fae[k] = (short)S.fe[bit0 + j - 1];
-                S.hi[k] = sb + j * dc;
+                S.hi[k] = sb + j * gs;
                 S.fbm[k] = (float)S.fm[bit0 + j];
                 S.fbe[k] = (short)S.fe[bit0 + j];
-                const double nr = sb + (j - 0.5) * dc;
+                // the root inside the bracket, by the secant of the tracked values at its ends
+                int de = S.fe[bit0 + j] - S.fe[bit0 + j - 1];
+                de = de > 60 ? 60 : (de < -60 ? -60 : de);
+                const double rho = ldexp(S.fm[bit0 + j] / S.fm[bit0 + j - 1], de);  // negative
+                double frac = 1.0 / (1.0 - rho);
+                frac = frac > 0.05 ? (frac < 0.95 ? frac : 0.95) : 0.05;
+                const double nr = sb + (j - 1 + frac) * gs;
                 inc = (nr - rprev) / dc;
                 have_inc = true;
                 if (use_hint) {
