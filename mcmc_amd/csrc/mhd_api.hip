@@ -162,15 +162,22 @@ __device__ inline void cov_accumulate_wave(const mhd_chains_t& ch, int ib, int N
 // forwards; a level that runs out falls back one level.  Every level returns the same curve.
 // Proposals that move the curve little start their forward model with predict_hint: those
 // whose Cauchy draw is at most hint_limit[perturbed parameter] in magnitude.  The limit adapts,
-// per chain and parameter: it grows by a quarter when predict_hint settles and drops to half the
-// draw that made it give up.  (A tuning state only: every path returns the same curve.)
+// per chain and parameter: it grows by half when predict_hint settles and drops to 0.7 of the
+// draw that made it give up (giving up costs a third of what settling saves, so the limit may
+// be bold).  (A tuning state only: every path returns the same curve.)
 #ifndef HINT_SECANT_CAUCHY
 #define HINT_SECANT_CAUCHY 1.0
 #endif
+#ifndef HLIM_GROW
+#define HLIM_GROW 1.5f
+#endif
+#ifndef HLIM_SHRINK
+#define HLIM_SHRINK 0.7f
+#endif
 __device__ __forceinline__ void hint_limit_update(float* limit, int kk, double cz, int hinted)
 {
-    if (hinted == 1) limit[kk] = fminf(limit[kk] * 1.25f, 16.0f);
-    if (hinted == 2) limit[kk] = fmaxf(0.5f * (float)fabs(cz), 0.01f);
+    if (hinted == 1) limit[kk] = fminf(limit[kk] * HLIM_GROW, 64.0f);
+    if (hinted == 2) limit[kk] = fmaxf(HLIM_SHRINK * (float)fabs(cz), 0.01f);
 }
 
 struct SearchPolicy {

@@ -629,7 +629,7 @@ __device__ MHD_NOINLINE void predict_refine(int wave, const double* t, int kbeg,
 
 // longest extrapolation step of predict_hint, in dc
 #ifndef HINT_STEP_MAX
-#define HINT_STEP_MAX 4.0
+#define HINT_STEP_MAX 12.0
 #endif
 
 // ---- stages 1 and 2 in one, from a hint ---------------------------------------------
