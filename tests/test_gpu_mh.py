@@ -163,6 +163,61 @@ def test_scheduled_launches_do_not_change_the_chains(oracle, candidates):
     assert n4_seen > 0   # the schedule really gave some chains four candidates
 
 
+def test_scheduled_rotated_launches_do_not_change_the_chains(oracle, candidates):
+    """The deadline of a scheduled call cuts chains between two steps of rotated-frame proposals
+    with covariance accumulation: the second launch must go on exactly there (cov_sum, n_cov,
+    params_prev, per-parameter counters and the history are booked per step)."""
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    if candidates != 2:
+        pytest.skip("scheduling applies to the default number of candidates")
+    rng = np.random.default_rng(11)
+    nl, P, B, S = 4, 20, 128, 120
+    NP = 2 * nl + 1
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
+    prob0 = DeviceProblem(nl, 1.75, periods)
+    starts = np.empty((0, NP))
+    while starts.shape[0] < B:
+        cand = np.array([oracle.sort_layers(x, nl)
+                         for x in rng.uniform(bounds[:, 0], bounds[:, 1], size=(2 * B, NP))])
+        _, st = prob0.forward(torch.tensor(cand, device=prob0.device))
+        starts = np.concatenate([starts, cand[st.cpu().numpy() == 0]])
+    starts = starts[:B]
+    obs = oracle.forward(starts[0], nl, 1.75, periods)[1] + 0.025 * rng.standard_normal(P)
+    prob = DeviceProblem(nl, 1.75, periods, obs, "normal", {"std": 0.025}, bounds)
+    dev = prob.device
+    rot = torch.tensor(np.stack([np.linalg.qr(rng.standard_normal((NP, NP)))[0]
+                                 for _ in range(B)]), device=dev)
+    idx = torch.tensor(rng.integers(0, NP, (S, B)).astype(np.int32), device=dev)
+    cauchy = torch.tensor(np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5)), device=dev)
+    u_acc = torch.tensor(rng.uniform(size=(S, B)), device=dev)
+    results, cut = [], 0
+    for scheduled in (True, False):
+        ch = DeviceChains(prob, starts, 0.04)
+        if not scheduled:
+            ch.sched = None
+        ch.rot.copy_(rot)
+        assert int((ch.init_likelihood() != 0).sum()) == 0
+        hist = []
+        for a in range(0, S, 40):
+            out = ch.steps(idx[a:a + 40], cauchy[a:a + 40], u_acc[a:a + 40], rotate=3,
+                           hist_every=8)
+            hist.append(torch.cat([out["accepted"].flatten().to(torch.float64),
+                                   out["status"].flatten().to(torch.float64),
+                                   out["hist_logL"].flatten(), out["hist_m"].flatten()]))
+            if scheduled:  # chains the second launch of the call found unfinished
+                cut = max(cut, int(ch.sched[4 * B + 20:4 * B + 24].view(torch.int32)[0]))
+        results.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(),
+                        ch.cov_sum.clone(), ch.n_cov.clone(), ch.params_prev.clone(),
+                        torch.cat(hist), int(ch.n_evals[0])))
+    a, b = results
+    for x, y in zip(a[:8], b[:8]):
+        assert torch.equal(x, y)
+    assert a[8] == b[8]
+    assert cut > 0   # the deadline really cut chains in the middle of a call
+
+
 def test_batched_rotated_steps_vs_oracle(oracle):
     """Rotated-frame proposals with covariance accumulation on every step, many steps per launch
     (the settling order of the steps matters for cov_sum / params_prev)."""
