@@ -973,13 +973,19 @@ int mhd_debug_profile(unsigned long long* out16, int reset)
 {
     hipDeviceSynchronize();
     if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[48] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    if (reset) { unsigned long long z[64] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
     return 0;
 }
 int mhd_debug_chain(unsigned int* out32768)
 {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out32768, HIP_SYMBOL(g_chain), 32768 * sizeof(unsigned int));
+    return 0;
+}
+int mhd_debug_profile_hi3(unsigned long long* out16)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long), 48 * sizeof(unsigned long long));
     return 0;
 }
 int mhd_debug_profile_hi2(unsigned long long* out16)

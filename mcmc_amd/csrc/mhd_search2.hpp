@@ -93,7 +93,7 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
 #pragma clang fp contract(off)
 
 #ifdef MHD_PROFILE
-__device__ unsigned long long g_prof[48];
+__device__ unsigned long long g_prof[64];
 __device__ unsigned long long g_times[4096];
 __device__ unsigned long long g_blk[1024 * 8];
 __device__ unsigned int g_chain[1024 * 32];  // event counts per chain, see CHAIN_EVENT
@@ -101,10 +101,14 @@ __device__ unsigned int g_chain[1024 * 32];  // event counts per chain, see CHAI
 #define PROF_T0 long long _t0 = clock64();
 #define PROF_ADD(i) { long long _t1 = clock64(); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_prof[i], (unsigned long long)(_t1 - _t0)); const int _ps = g_PS.prof_slot; if (_ps >= 0 && _ps < 1024) atomicAdd(&g_blk[_ps * 8 + i], (unsigned long long)(_t1 - _t0)); } _t0 = _t1; }
 #define HINT_WHY(i) if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[i], 1ull);
+#define REPLAY_T0 long long _rt0 = clock64();
+#define REPLAY_ADD(i) { const long long _rt1 = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[i], (unsigned long long)(_rt1 - _rt0)); _rt0 = _rt1; }
 #else
 #define PROF_T0
 #define PROF_ADD(i)
 #define CHAIN_EVENT(i) {}
+#define REPLAY_T0
+#define REPLAY_ADD(i)
 #define HINT_WHY(i)
 #endif
 

@@ -28,6 +28,7 @@ nst=750.0
 out=(ctypes.c_ulonglong*16)(); hh=(ctypes.c_ulonglong*16)(); lib.mhd_debug_profile_hi(hh); lib.mhd_debug_profile(out,0); o=list(out); print("coarse: calls %d rounds/call %.2f hint kept %.2f | hint-secant calls %d failed %.4f"%(o[15], o[14]/max(o[15],1), o[13]/max(o[15],1), o[11], o[12]/max(o[11],1)), end=" "); h=hh; print("failed %d after %.2f rounds, done %d after %.2f rounds"%(h[0],h[3]/max(h[0],1),h[2],h[1]/max(h[2],1)))
 h2=(ctypes.c_ulonglong*16)(); lib.mhd_debug_profile_hi2(h2); n_=max(o[15],1); print("coarse per call: first-period rounds %.2f, shaped rounds %.2f resolving %.2f periods each, lattice rounds %.2f resolving %.2f each, carry rounds %.2f, with hint %.2f, hint misses %.2f"%(h2[0]/n_, h2[1]/n_, h2[2]/max(h2[1],1), h2[3]/n_, h2[4]/max(h2[3],1), h2[5]/n_, h2[6]/n_, h2[7]/n_))
 print("shaped-round failures: no sign change in the window %d, several %d; failing q mean %.2f; failures at q<2 by period <10/<20/<30/>=30: %s"%(h2[8],h2[9],h2[10]/max(h2[8]+h2[9],1),[int(v) for v in h2[12:16]]))
+h3=(ctypes.c_ulonglong*16)(); lib.mhd_debug_profile_hi3(h3); nr_=max(h3[5],1); print("replay per period (cycles): set-up %.0f, scan %.0f, halvings without the test %.0f, halvings with it %.0f, finish %.0f (periods %d)"%(h3[0]/nr_,h3[1]/nr_,h3[2]/nr_,h3[3]/nr_,h3[4]/nr_,h3[5]))
 print("max shift/dc histogram (<.25,<.5,<1,<2,<4,<8,<16,<32,<64,<128,more):", [int(v) for v in hh[5:16]])
 print("round: scan+forward cycles %.3g, barrier wait cycles %.3g (%.3f of the sum)"%(o[10],o[9],o[9]/(o[9]+o[10])))
 print("per chain over 750 steps: rounds/step mean %.3f, forwards/step %.3f, sequential-search share %.3f"%(b[:,0].mean()/nst, b[:,1].mean()/nst, b[:,2].sum()/b[:,1].sum()))
