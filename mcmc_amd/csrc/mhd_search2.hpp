@@ -827,19 +827,18 @@ __device__ __forceinline__ int replay_period(int k, double& c1io, double clow, d
         if (ifirst) CHAIN_EVENT(3)
         return -1;
     }
-    // The halvings.  This is a chain of dependent FP64 operations, which is what its time is made
-    // of, so the chain is kept short.  (1) The stopping test |c1 - c2| <= 1e-6 c1 cannot succeed
-    // while the ends are more than 2^-19 of the larger one apart (2^-19 > 1e-6): for that many
-    // halvings, counted from the binary exponents, it is left out, and with it the branch that
-    // waits for it.  (2) The next midpoint is computed for both outcomes of the current one
-    // while the current one is being compared with the root: with h = c / 2 for both ends,
-    // RN((c3 + c1) / 2) = fma(0.5, c3, h1) bit for bit (halving is exact, the sum is rounded
-    // once either way), so a halving costs one fma and one select in the chain.  The
-    // verification pass checks every abscissa and every side taken here against the plain
-    // 0.5 * (c1 + c2) arithmetic of replay_abscissa.
+    // The halvings.  (1) The stopping test |c1 - c2| <= 1e-6 c1 cannot succeed while the ends are
+    // more than 2^-19 of the larger one apart (2^-19 > 1e-6): for that many halvings, counted
+    // from the binary exponents, it is left out.  (2) Those halvings run in the scalar unit, on
+    // the bit patterns of the (positive, wave-uniform) doubles -- the vector unit is what limits
+    // the throughput of these kernels, and this loop is a fifth of a curve's vector instructions
+    // otherwise.  Within one binade the pattern of RN((c1 + c2) / 2) is the mean of the patterns,
+    // rounded half to even; positive doubles compare like their patterns (the borrow of a
+    // subtraction decides: the scalar unit has no ordered 64-bit compare).  The ends stay inside
+    // the binade they start in.  The verification pass checks every abscissa and every side
+    // taken here against the plain 0.5 * (c1 + c2) arithmetic of replay_abscissa.
     unsigned long long bits = 0;
     int nh = 0;
-    double c3 = 0.5 * (c1 + c2);
     {
         const int e_apart = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fabs(c1 - c2)));
         const int e_ends = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fmax(c1, c2)));
@@ -847,21 +846,61 @@ __device__ __forceinline__ int replay_period(int k, double& c1io, double clow, d
         // are at least 2^(e_apart - 1 - n - e_ends) of the larger one apart
         int sure = e_apart - 1 - e_ends + 19;
         sure = sure < 0 ? 0 : (sure > 38 ? 38 : sure);
-        double h1 = 0.5 * c1, h2 = 0.5 * c2;
+        unsigned b1l = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(c1));
+        unsigned b1h = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(c1));
+        unsigned b2l = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(c2));
+        unsigned b2h = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(c2));
+        const unsigned blol = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(lo));
+        const unsigned bloh = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(lo));
+        // (below1 as a 0/1 word in a scalar register: made from the vote itself, a select on the
+        // flag ends up in a vector register whatever the constraint says)
+        unsigned bel;
+        {
+            const unsigned long long vote = __ballot(start <= lo) | (unsigned long long)0;
+            asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(bel) : "s"(vote) : "scc");
+        }
+        if (((b1h ^ b2h) >> 20) != 0u) sure = 0;  // the ends are in two binades: all by the FP loop
+        unsigned long long sbits = 0;
         for (int i = 0; i < sure; ++i) {
-            const bool left = (c3 <= lo) != below1;  // the sign at c3 differs from the one at c1
-            const double h3 = 0.5 * c3;
-            const double next_left = __builtin_fma(0.5, c3, h1);   // the ends become c1, c3
-            const double next_right = __builtin_fma(0.5, c3, h2);  // the ends become c3, c2
-            bits |= (unsigned long long)left << nh;
+            unsigned sl, sh, m3l, m3h, tt;
+            unsigned long long left64;
+            asm volatile(
+                "s_add_u32 %[sl], %[b1l], %[b2l]\n\t"
+                "s_addc_u32 %[sh], %[b1h], %[b2h]\n\t"
+                "s_lshr_b32 %[m3l], %[sl], 1\n\t"
+                "s_lshl_b32 %[tt], %[sh], 31\n\t"
+                "s_or_b32 %[m3l], %[m3l], %[tt]\n\t"
+                "s_lshr_b32 %[m3h], %[sh], 1\n\t"
+                "s_and_b32 %[tt], %[sl], %[m3l]\n\t"
+                "s_and_b32 %[tt], %[tt], 1\n\t"
+                "s_add_u32 %[m3l], %[m3l], %[tt]\n\t"
+                "s_addc_u32 %[m3h], %[m3h], 0\n\t"
+                "s_sub_u32 %[tt], %[blol], %[m3l]\n\t"
+                "s_subb_u32 %[tt], %[bloh], %[m3h]\n\t"
+                "s_cselect_b32 %[tt], 0, 1\n\t"
+                "s_xor_b32 %[tt], %[tt], %[bel]\n\t"
+                "s_cselect_b32 %[b2l], %[m3l], %[b2l]\n\t"
+                "s_cselect_b32 %[b2h], %[m3h], %[b2h]\n\t"
+                "s_cselect_b32 %[b1l], %[b1l], %[m3l]\n\t"
+                "s_cselect_b32 %[b1h], %[b1h], %[m3h]\n\t"
+                "s_cselect_b64 %[left64], 1, 0\n\t"
+                "s_lshl_b64 %[left64], %[left64], %[nh]\n\t"
+                "s_or_b64 %[sbits], %[sbits], %[left64]"
+                : [sl] "=&s"(sl), [sh] "=&s"(sh), [m3l] "=&s"(m3l), [m3h] "=&s"(m3h),
+                  [tt] "=&s"(tt), [left64] "=&s"(left64), [b1l] "+s"(b1l), [b1h] "+s"(b1h),
+                  [b2l] "+s"(b2l), [b2h] "+s"(b2h), [sbits] "+s"(sbits)
+                : [blol] "s"(blol), [bloh] "s"(bloh), [bel] "s"(bel), [nh] "s"(nh)
+                : "scc");
+            // (bit nh of sbits: the sign at the midpoint differs from the one at c1)
             ++nh;
-            c2 = left ? c3 : c2;
-            h2 = left ? h3 : h2;
-            c1 = left ? c1 : c3;
-            h1 = left ? h1 : h3;
-            c3 = left ? next_left : next_right;
+        }
+        if (sure > 0) {
+            c1 = __hiloint2double((int)b1h, (int)b1l);
+            c2 = __hiloint2double((int)b2h, (int)b2l);
+            bits = sbits;
         }
     }
+    double c3 = 0.5 * (c1 + c2);
     double last;
     for (;;) {
         const bool left = uni(c3 <= lo) != below1;
