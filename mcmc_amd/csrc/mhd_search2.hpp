@@ -64,8 +64,13 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
 
 // A secant iterate x(n+1) is within about C |x(n+1)-x(n)| |x(n+1)-x(n-1)| of the root; with this
 // bound on the product it is taken as the root without being evaluated (C, the curvature over
-// twice the slope, is some tens per km/s; the replay wants 1e-12)
-#define ROOT_ERR_PRODUCT 2.0e-14
+// twice the slope, is some tens per km/s).  The replay infers a wrong sign only for an abscissa
+// between the root and its estimate; the halving abscissae come no closer to a root than some
+// 1e-7 of it as a rule, so an estimate good to a few 1e-11 fails about one curve in a thousand,
+// which the verification repairs.
+#ifndef ROOT_ERR_PRODUCT
+#define ROOT_ERR_PRODUCT 1.0e-12
+#endif
 
 // hint steps (in dc) from which predict_coarse spaces the abscissae of a window 2 and 4 dc apart
 #ifndef WIDE_STEP_2
@@ -631,6 +636,11 @@ __device__ MHD_NOINLINE void predict_refine(int wave, const double* t, int kbeg,
     wave_sync();
 }
 
+// second abscissa of predict_hint: this many dc above the hint
+#ifndef HINT_SECOND_POINT
+#define HINT_SECOND_POINT 0.1
+#endif
+
 // longest extrapolation step of predict_hint, in dc
 #ifndef HINT_STEP_MAX
 #define HINT_STEP_MAX 12.0
@@ -676,7 +686,7 @@ __device__ MHD_NOINLINE int predict_hint(int wave, const double* t, int P, doubl
             if (it == 0) {
                 x = h;
             } else if (it == 1) {
-                x = h + 0.5 * dc;
+                x = h + HINT_SECOND_POINT * dc;
             } else {
                 double xs = secant(x0, f0, e0, x1, f1, e1);
                 // bracketed: inside the bracket, else an Illinois step on its ends
