@@ -72,6 +72,11 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
 #define ROOT_ERR_PRODUCT 1.0e-12
 #endif
 
+// half-width, in abscissae, of the first window of a round that the hint places
+#ifndef SHAPED_BASE_M
+#define SHAPED_BASE_M 2
+#endif
+
 // hint steps (in dc) from which predict_coarse spaces the abscissae of a window 2 and 4 dc apart
 #ifndef WIDE_STEP_2
 #define WIDE_STEP_2 3.0
@@ -180,7 +185,7 @@ __device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, 
                 const double hstep = fabs(hint[k0 + q] - hint[k0 + q - 1]);
                 path += hstep;
                 const double gs = (hstep < WIDE_STEP_2 * dc ? 1.0 : (hstep < WIDE_STEP_4 * dc ? 2.0 : 4.0)) * dc;
-                int m = 2 + q / 2 + (int)((HINT_STRETCH * path + HINT_TREND_SLACK * (q + 1) * fabs(trend)) / gs);
+                int m = SHAPED_BASE_M + q / 2 + (int)((HINT_STRETCH * path + HINT_TREND_SLACK * (q + 1) * fabs(trend)) / gs);
                 m = m > 15 ? 15 : m;
                 if (off + 2 * m + 1 > 64) {
                     if (q > 0) break;
