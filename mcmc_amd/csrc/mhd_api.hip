@@ -473,6 +473,7 @@ __host__ __device__ inline SchedView sched_view(void* buf, int B)
 #define SCHED_PHASES_N 2
 #endif
 constexpr int SCHED_PHASES = SCHED_PHASES_N;
+constexpr int SCHED_PHASES_MIN_STEPS = 96;  // calls of fewer steps are one launch
 #ifndef PHASE_DEADLINE_LATER
 #define PHASE_DEADLINE_LATER 1.0f  // later deadlines, in units of the median unfinished chain's
 #endif
@@ -481,7 +482,7 @@ constexpr int SCHED_PHASES = SCHED_PHASES_N;
 #endif
 
 __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S, int phase,
-                                                        int slots)
+                                                        int phases, int slots)
 {
     __shared__ float key[SCHED_MAX_CHAINS];
     __shared__ int val[SCHED_MAX_CHAINS];
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
                 ++n4;
                 nsplit = ns;
             }
-            if (PHASE_DEADLINE_FRACTION > 0.0f)
+            if (PHASE_DEADLINE_FRACTION > 0.0f && phases > 1)
                 deadline = (unsigned long long)wall_clock64() +
                            (unsigned long long)(PHASE_DEADLINE_FRACTION * key[B / 2] * (float)S /
                                                 SCHED_CONSUMED[2]);
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
             n4 = room < 0 ? 0 : (room < left ? room : left);
             const int cap = sched_cap4(B, phase);
             if (n4 > cap) n4 = cap;
-            if (phase < SCHED_PHASES - 1 && left > 0)
+            if (phase < phases - 1 && left > 0)
                 deadline = (unsigned long long)wall_clock64() +
                            (unsigned long long)(PHASE_DEADLINE_LATER * key[left / 2] /
                                                 SCHED_CONSUMED[left / 2 < n4 ? 4 : 2]);
@@ -1095,9 +1096,11 @@ int mhd_mh_steps(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t 
             e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps device");
         const int slots = cus * 8;  // two waves of these kernels per SIMD
-        for (int phase = 0; phase < SCHED_PHASES; ++phase) {
+        // (a short call is one launch: a deadline and a second launch cost more than they even out)
+        const int phases = n_steps >= SCHED_PHASES_MIN_STEPS ? SCHED_PHASES : 1;
+        for (int phase = 0; phase < phases; ++phase) {
             hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, chains->sched, B,
-                               n_steps, phase, slots);
+                               n_steps, phase, phases, slots);
             e = hipEventRecord(side->fork, s);
             if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
             if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps fork");

@@ -54,7 +54,7 @@ def test_chains_every_way_of_running_agrees_at_full_size():
     obs = prob0.forward(torch.tensor(starts[:1], device=prob0.device))[0][0].cpu().numpy() \
         + 0.025 * rng.standard_normal(P)
     prob = DeviceProblem(NL, 1.75, periods, obs, "normal", {"std": 0.025}, bounds)
-    dev, NP, S = prob.device, 2 * NL + 1, 120
+    dev, NP, S = prob.device, 2 * NL + 1, 240   # two calls of 120 steps: the second is two launches
     idx = torch.tensor(rng.integers(0, NP, (S, B)).astype(np.int32), device=dev)
     cauchy = torch.tensor(np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5)), device=dev)
     u_acc = torch.tensor(rng.uniform(size=(S, B)), device=dev)
@@ -68,8 +68,8 @@ def test_chains_every_way_of_running_agrees_at_full_size():
             ch.sched = None
         assert int((ch.init_likelihood() != 0).sum()) == 0
         acc = []
-        for a in range(0, S, 40):
-            out = ch.steps(idx[a:a + 40], cauchy[a:a + 40], u_acc[a:a + 40])
+        for a in range(0, S, 120):
+            out = ch.steps(idx[a:a + 120], cauchy[a:a + 120], u_acc[a:a + 120])
             acc.append(out["accepted"])
         results.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(),
                         torch.cat(acc), int(ch.n_evals[0])))

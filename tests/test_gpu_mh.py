@@ -172,7 +172,7 @@ def test_scheduled_rotated_launches_do_not_change_the_chains(oracle, candidates)
     if candidates != 2:
         pytest.skip("scheduling applies to the default number of candidates")
     rng = np.random.default_rng(11)
-    nl, P, B, S = 4, 20, 128, 120
+    nl, P, B, S = 4, 20, 128, 240   # calls of 120 steps: long enough to be made of two launches
     NP = 2 * nl + 1
     periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
     bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
@@ -200,8 +200,8 @@ def test_scheduled_rotated_launches_do_not_change_the_chains(oracle, candidates)
         ch.rot.copy_(rot)
         assert int((ch.init_likelihood() != 0).sum()) == 0
         hist = []
-        for a in range(0, S, 40):
-            out = ch.steps(idx[a:a + 40], cauchy[a:a + 40], u_acc[a:a + 40], rotate=3,
+        for a in range(0, S, 120):
+            out = ch.steps(idx[a:a + 120], cauchy[a:a + 120], u_acc[a:a + 120], rotate=3,
                            hist_every=8)
             hist.append(torch.cat([out["accepted"].flatten().to(torch.float64),
                                    out["status"].flatten().to(torch.float64),
