@@ -1024,9 +1024,9 @@ int mhd_secular_batch(const mhd_problem_t* prob, const double* params, int32_t B
                       double* delta, void* stream)
 {
     if (int rc = check_problem(prob, false)) return rc;
-    if (!params || !chain || !period || !c || !delta) return fail(MHD_EINVAL, "NULL argument");
     if (B < 0 || N < 0) return fail(MHD_EINVAL, "negative size");
-    if (N == 0) return MHD_OK;
+    if (N == 0) return MHD_OK;  // (an empty batch may come with NULL arrays)
+    if (!params || !chain || !period || !c || !delta) return fail(MHD_EINVAL, "NULL argument");
     hipLaunchKernelGGL(secular_kernel, dim3(N), dim3(64), WAVE_LDS_BYTES, (hipStream_t)stream, *prob, params, B,
                        chain, period, c, N, delta);
     hipError_t e = hipGetLastError();
@@ -1037,9 +1037,9 @@ int mhd_forward_batch(const mhd_problem_t* prob, const double* params, int32_t B
                       int32_t* status, uint64_t* n_evals, void* stream)
 {
     if (int rc = check_problem(prob, false)) return rc;
-    if (!params || !vel || !status) return fail(MHD_EINVAL, "NULL argument");
     if (B < 0) return fail(MHD_EINVAL, "negative batch");
-    if (B == 0) return MHD_OK;
+    if (B == 0) return MHD_OK;  // (an empty batch may come with NULL arrays)
+    if (!params || !vel || !status) return fail(MHD_EINVAL, "NULL argument");
     hipLaunchKernelGGL(forward_kernel, dim3(B), dim3(64), WAVE_LDS_BYTES, (hipStream_t)stream, *prob, params, B,
                        vel, status, (unsigned long long*)n_evals, g_search);
     hipError_t e = hipGetLastError();
@@ -1050,9 +1050,9 @@ int mhd_loglik_batch(const mhd_problem_t* prob, const double* pred, int32_t B, d
                      void* stream)
 {
     if (int rc = check_problem(prob, true)) return rc;
-    if (!pred || !logL) return fail(MHD_EINVAL, "NULL argument");
     if (B < 0) return fail(MHD_EINVAL, "negative batch");
-    if (B == 0) return MHD_OK;
+    if (B == 0) return MHD_OK;  // (an empty batch may come with NULL arrays)
+    if (!pred || !logL) return fail(MHD_EINVAL, "NULL argument");
     hipLaunchKernelGGL(loglik_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *prob, pred, B,
                        logL);
     hipError_t e = hipGetLastError();
@@ -1078,10 +1078,10 @@ int mhd_mh_steps(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t 
 {
     if (int rc = check_problem(prob, true)) return rc;
     if (int rc = check_chains(chains, rotate)) return rc;
-    if (!idx || !cauchy || !u_acc) return fail(MHD_EINVAL, "draw array is NULL");
     if (B < 0 || n_steps < 0 || hist_every < 0) return fail(MHD_EINVAL, "negative size");
     if (!(T > 0.0)) return fail(MHD_EINVAL, "T must be positive");
-    if (B == 0 || n_steps == 0) return MHD_OK;
+    if (B == 0 || n_steps == 0) return MHD_OK;  // (no steps may come with NULL draw arrays)
+    if (!idx || !cauchy || !u_acc) return fail(MHD_EINVAL, "draw array is NULL");
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* ne = (unsigned long long*)n_evals;
     if (g_candidates == 2 && !sample_prior && chains->sched && B >= 64 &&

@@ -35,6 +35,11 @@ def test_argument_validation_without_gpu():
     assert rc == -22 and b"n_layers" in lib.mhd_last_error()
     p = L.Problem(n_layers=3, n_periods=4000, dc=0.005)
     assert lib.mhd_forward_batch(ctypes.byref(p), None, 1, None, None, None, None) == -22
+    # NULL arrays: an error for a batch, nothing to do for an empty one
+    p = L.Problem(n_layers=3, n_periods=8, dc=0.005, dt=0.025, vpvs=1.75, periods=1)
+    assert lib.mhd_forward_batch(ctypes.byref(p), None, 1, None, None, None, None) == -22
+    assert lib.mhd_forward_batch(ctypes.byref(p), None, 0, None, None, None, None) == 0
+    assert lib.mhd_forward_batch(ctypes.byref(p), None, -1, None, None, None, None) == -22
     with pytest.raises(L.MhdError):
         L.check(-22)
 
