@@ -580,9 +580,17 @@ __device__ MHD_NOINLINE int phase_curve_wave(const LayerTable& T, int wave, cons
                 clow = cc;
                 c1 = cc;
             } else if (ifirst && iq > 0) {
+                if (uni(c[0] == 0.0)) break;  // the mode below has no root at all: neither has this
                 c1 = c[0] + one * dc;
                 clow = c1;
             } else if (!ifirst && iq > 0) {
+                // c[k] is still the mode below: past its cut-off this mode has none either
+                // (cut-off periods shrink with the mode number), and a search from c = 0 upward
+                // would run through wavenumbers where the secular function is rounding noise
+                if (uni(c[k] == 0.0)) {
+                    for (int i = k; i < P; ++i) c[i] = 0.0;
+                    break;
+                }
                 clow = c[k] + one * dc;
                 c1 = c[k - 1];
                 if (c1 < clow) c1 = clow;
