@@ -98,3 +98,60 @@ def test_mh_steps_at_the_limits_match_the_oracle(oracle, B):
     np.testing.assert_array_equal(ch.m.cpu().numpy(), ost.m)
     np.testing.assert_allclose(ch.logL.cpu().numpy(), ost.logL, rtol=1e-9, atol=1e-9)
     np.testing.assert_array_equal(ch.counters.cpu().numpy(), ost.counters)
+
+
+def test_sample_prior_and_curve_history(oracle):
+    """sample_prior steps (no forward model, logL_new = 1: model.py:234-236) against the oracle,
+    and the per-step records: the last record of every history equals the final state."""
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    rng = np.random.default_rng(23)
+    nl, P, B, S = 3, 12, 80, 30
+    NP = 2 * nl + 1
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
+    starts = []
+    while len(starts) < B:
+        x = _draws(rng, 1, nl)[0]
+        if oracle.forward(x, nl, 1.75, periods)[0] == 0:
+            starts.append(x)
+    starts = np.array(starts)
+    obs = oracle.forward(starts[0], nl, 1.75, periods)[1] + 0.025 * rng.standard_normal(P)
+    noise = {"std": 0.025}
+    prob = DeviceProblem(nl, 1.75, periods, obs, "normal", noise, bounds)
+    dev = prob.device
+    idx = rng.integers(0, NP, (S, B)).astype(np.int32)
+    cauchy = np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5))
+    u_acc = rng.uniform(size=(S, B))
+    t = lambda a: torch.tensor(a, device=dev)
+    _, ovel, _ = oracle.forward_batch(starts, nl, 1.75, periods)
+    ologL = np.array([oracle.loglik(obs, v, "normal", noise) for v in ovel])
+
+    # sample_prior
+    ch = DeviceChains(prob, starts, 0.05)
+    assert int((ch.init_likelihood() != 0).sum()) == 0
+    ost = oracle.ChainState(starts, ologL, ovel, 0.05, bounds)
+    out = ch.steps(t(idx), t(cauchy), t(u_acc), sample_prior=True)
+    acc = np.zeros((S, B), dtype=np.uint8)
+    for s in range(S):
+        acc[s], _, _ = oracle.mh_step(ost, idx[s], cauchy[s], u_acc[s], nl, 1.75, periods, obs,
+                                      "normal", noise, sample_prior=True)
+    np.testing.assert_array_equal(out["accepted"].cpu().numpy(), acc)
+    np.testing.assert_array_equal(ch.m.cpu().numpy(), ost.m)
+    np.testing.assert_array_equal(ch.counters.cpu().numpy(), ost.counters)
+    assert acc.sum() > 0
+
+    # histories of a normal run
+    ch = DeviceChains(prob, starts, 0.05)
+    ch.init_likelihood()
+    out = ch.steps(t(idx), t(cauchy), t(u_acc), hist_every=5, want_pred_hist=True)
+    assert out["hist_m"].shape == (S // 5, B, NP)
+    assert torch.equal(out["hist_m"][-1], ch.m)
+    assert torch.equal(out["hist_logL"][-1], ch.logL)
+    assert torch.equal(out["hist_pred"][-1], ch.pred)
+    # a record in the middle: the state after 15 steps of the same draws
+    ch2 = DeviceChains(prob, starts, 0.05)
+    ch2.init_likelihood()
+    ch2.steps(t(idx[:15]), t(cauchy[:15]), t(u_acc[:15]))
+    assert torch.equal(out["hist_m"][2], ch2.m)
+    assert torch.equal(out["hist_pred"][2], ch2.pred)
