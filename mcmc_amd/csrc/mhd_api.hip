@@ -599,7 +599,9 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     __shared__ double test[NW][MAXNP];  // candidate of each wave
     __shared__ double tmp[NW][MAXNP];
     __shared__ double newpred[NW][MAXP];
-    __shared__ double scratch[NW][2 * MAXP];
+    __shared__ double scratch[NW][3 * MAXP];  // two phase curves (group velocity), likelihood terms
+    __shared__ double ghint_[NG][2 * MAXP];   // group velocity: the two phase curves of the current state
+    __shared__ int ghint_ok_[NG];
     __shared__ int r_step[NW], r_st[NW], r_trouble[NW], r_stop[NW];
     __shared__ double r_logL[NW];
     __shared__ unsigned long long r_lit[NW];
@@ -637,6 +639,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     double* wid = wid_[g];
     double* pred = pred_[g];
     float* hlim = hlim_[g];
+    double* ghint = ghint_[g];
 
     const long long t_begin = wall_clock64();
     const int nl = p.n_layers, NP = 2 * nl + 1, P = p.n_periods;
@@ -687,7 +690,31 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         (void)hw; (void)xcc;
     }
 #endif
+    // Group velocity: the two phase curves of the current state guide the predictor as the
+    // current curve does for phase velocity, but they are not part of a chain's state: the
+    // chain's first wave computes them once per launch (and on every acceptance they are the
+    // candidate's).
+    if (writer && lane == 0) ghint_ok_[g] = 0;
+    if (p.itype == MHD_GROUP && p.mode == 0 && search == 2 && writer) {
+        wave_sync();
+        build_layer_table(T, m, nl, p.vpvs, lane);
+        EvalCount extra = {0, 0};
+        const int st0 = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
+                                          scratch[w], extra, 0, t, 0);
+        wave_sync();
+        if (st0 == MHD_ST_OK)
+            for (int k = lane; k < 2 * P; k += 64) ghint[k] = scratch[w][k];
+        if (lane == 0) ghint_ok_[g] = (st0 == MHD_ST_OK);
+        exec += extra.exec;
+        wave_sync();
+    }
     group_sync();
+    const bool hinted = p.mode == 0 && (p.itype == MHD_PHASE || ghint_ok_[g] != 0);
+    if (search == 2 && hinted) {
+        policy.max_level = 0;
+        policy.level = 0;
+        policy.left = 0;
+    }
 
     // everything one step leaves behind besides the state itself (the chain's first wave writes)
     auto book = [&](int j, int st, int acc) {
@@ -739,6 +766,8 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
                         mn[lane] = (m[lane] - lo[lane]) / rg[lane];
                     }
                     for (int k = lane; k < P; k += 64) pred[k] = newpred[c][k];
+                    if (p.itype == MHD_GROUP)
+                        for (int k = lane; k < 2 * P; k += 64) ghint[k] = scratch[c][k];
                     wave_sync();
                 }
                 logL = lnew;
@@ -790,8 +819,9 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             build_layer_table(T, test[w], nl, p.vpvs, lane);
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
-                                       scratch[w], cnt, policy.stepwise(), pred,
-                                       p.itype != MHD_PHASE ? 0 : (fabs(czc) <= hlim[kkc] ? 2 : 1));
+                                       scratch[w], cnt, policy.stepwise(),
+                                       p.itype == MHD_PHASE ? pred : ghint,
+                                       !hinted ? 0 : (fabs(czc) <= hlim[kkc] ? 2 : 1));
                 trouble = __builtin_amdgcn_readfirstlane(g_PS.trouble);
                 // (the waves of a chain update the limits unordered; they are heuristics)
                 if (lane == 0)
@@ -801,7 +831,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
                                   scratch[w], cnt);
             }
             wave_sync();
-            if (st == MHD_ST_OK) lnew = loglik_wave(p, newpred[w], scratch[w], lane);
+            if (st == MHD_ST_OK) lnew = loglik_wave(p, newpred[w], scratch[w] + 2 * MAXP, lane);
             exec += cnt.exec;
         }
         if (lane == 0) {

@@ -1263,9 +1263,12 @@ __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode,
     }
     double* c1 = scratch;
     double* c2 = scratch + P;
-    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt, stepwise, t, 0);
+    // (group velocity: the hint holds the two phase curves of the similar model, P values each)
+    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt, stepwise, use_hint ? hint : t,
+                                   use_hint);
     if (st != MHD_ST_OK) return st;
-    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt, stepwise, t, 0);
+    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt, stepwise, use_hint ? hint + P : t,
+                               use_hint);
     if (st != MHD_ST_OK) return st;
     for (int k = 0; k < P; ++k) {
         if (c1[k] > 0.0 && c2[k] > 0.0) {
