@@ -399,7 +399,7 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
     unsigned long long pneg = 0, ppos = 0;
     int pbase = 0;                    // first lane of the bracket's 3-level tree
 
-    // ---- round 1: 8 scan abscissae + 7 small trees (upward scan assumed) ----
+    // ---- first pass of the wave: 8 scan abscissae + 7 small trees (upward scan assumed) ----
     {
         // scan abscissa j (0..7) of the upward sequence
         double q1 = c1, pt = c1;
