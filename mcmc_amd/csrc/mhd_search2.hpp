@@ -137,7 +137,7 @@ __device__ __forceinline__ int mask_sign(unsigned long long neg, unsigned long l
 // differences between its periods -- places small windows around the expected roots, eight
 // periods per round; where that fails, and without a hint, the windows start at the expected
 // start of the sequential scan and are 8, 16, 32 or 64 abscissae wide.
-__device__ MHD_NOINLINE int predict_coarse(int wave, const double* t, int kbeg, int P,
+__device__ __forceinline__ int predict_coarse(int wave, const double* t, int kbeg, int P,
                                            double tscale, double dc, double rprev_in,
                                            int sigma0_in, const double* hint, bool use_hint,
                                            EvalCount& cnt)
@@ -527,7 +527,7 @@ __device__ MHD_NOINLINE int predict_stepwise(int wave, const double* t, int kbeg
 // ---- stage 2 ----------------------------------------------------------------
 // eval_ends: the brackets come with signs only (predict_stepwise); the tracked values at their
 // ends are evaluated first.
-__device__ MHD_NOINLINE void predict_refine(int wave, const double* t, int kbeg, int P,
+__device__ __forceinline__ void predict_refine(int wave, const double* t, int kbeg, int P,
                                             double tscale, EvalCount& cnt, bool eval_ends = false)
 {
     PredictScratch& S = g_PS;
@@ -659,7 +659,7 @@ __device__ MHD_NOINLINE void predict_refine(int wave, const double* t, int kbeg,
 // a period does not settle (the caller then uses predict_coarse): an iterate leaves
 // (floor, ceiling) or strays more than 16 dc from the hint, or the iteration is not done after
 // ten rounds.
-__device__ MHD_NOINLINE int predict_hint(int wave, const double* t, int P, double tscale,
+__device__ __forceinline__ int predict_hint(int wave, const double* t, int P, double tscale,
                                          double dc, const double* hint, EvalCount& cnt)
 {
     PredictScratch& S = g_PS;
