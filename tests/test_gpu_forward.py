@@ -50,6 +50,42 @@ def test_forward_matches_oracle(torch_cuda, oracle, n_layers, P, B):
           f"evals lit={int(ne[0])} exec={int(ne[1])}")
 
 
+@pytest.mark.parametrize("search", [2, 1])
+def test_forward_low_velocity_zones(torch_cuda, oracle, search):
+    """Models with strong low-velocity zones, where the sequential search changes branches and
+    its curve jumps downwards between periods: both device searches must land on the same lattice
+    points as the sequential algorithm, jumps included."""
+    torch = torch_cuda
+    from mcmc_amd import _lib as L
+    from mcmc_amd.engine import DeviceProblem
+    rng = np.random.default_rng(166)
+    nl, P, B = 6, 40, 512
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    base = np.array([0.03, 0.0339, 0.0494, 0.0627, 0.0643, 0.1304,
+                     0.1677, 0.526, 1.2108, 0.3184, 1.7798, 0.1555, 1.0089])
+    params = np.tile(base, (B, 1))
+    params[1:, :nl] *= 1.0 + 0.05 * rng.standard_normal((B - 1, nl))
+    params[1:, nl:] *= 1.0 + 0.10 * rng.standard_normal((B - 1, nl + 1))
+    params[:, :nl] = np.sort(params[:, :nl], axis=1)
+    params[:, nl:] = np.clip(params[:, nl:], 0.1, 2.0)
+    L.check(L.lib().mhd_set_search(search))
+    try:
+        prob = DeviceProblem(nl, 1.75, periods)
+        ne = torch.zeros(2, dtype=torch.int64, device=prob.device)
+        vel, status = prob.forward(torch.tensor(params, device=prob.device), n_evals=ne)
+    finally:
+        L.check(L.lib().mhd_set_search(2))
+    ost, ovel, one = oracle.forward_batch(params, nl, 1.75, periods, nthreads=8)
+    vel, status = vel.cpu().numpy(), status.cpu().numpy()
+    assert (status == ost).all()
+    ok = ost == 0
+    assert ok.sum() > B // 2
+    assert np.array_equal(vel[ok], ovel[ok])
+    assert int(ne[0]) == one
+    jumps = (np.diff(ovel[ok], axis=1) < 0).any(axis=1)   # curves that go down with the period
+    assert jumps.sum() > B // 8, int(jumps.sum())
+
+
 def test_forward_golden_curves(torch_cuda):
     """The disba curves embedded in the reference, straight through the HIP path."""
     torch = torch_cuda
