@@ -113,6 +113,60 @@ def test_batched_steps_vs_oracle(oracle, n_layers, P, B, S):
     assert (stat == 1).any()   # bounds rejections were exercised
 
 
+def test_steps_of_chains_in_low_velocity_zone_models_vs_oracle(oracle):
+    """Chains that start at models with strong low-velocity zones: their curves jump downwards
+    between periods, so the curve of the current state is a poor guide for the candidate's and
+    the predicted search has to repair and resynchronise.  Decisions and states must still be
+    those of the sequential algorithm."""
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    rng = np.random.default_rng(1660)
+    nl, NP, P, B, S = 6, 13, 40, 128, 100
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
+    base = np.array([0.03, 0.0339, 0.0494, 0.0627, 0.0643, 0.1304,
+                     0.1677, 0.526, 1.2108, 0.3184, 1.7798, 0.1555, 1.0089])
+    starts = []
+    while len(starts) < B:
+        x = base.copy()
+        x[:nl] *= 1.0 + 0.05 * rng.standard_normal(nl)
+        x[nl:] *= 1.0 + 0.10 * rng.standard_normal(nl + 1)
+        x = oracle.sort_layers(np.clip(x, bounds[:, 0], bounds[:, 1]), nl)
+        if oracle.forward(x, nl, 1.75, periods)[0] == 0:
+            starts.append(x)
+    starts = np.array(starts)
+    _, ovel, _ = oracle.forward_batch(starts, nl, 1.75, periods)
+    assert ((np.diff(ovel, axis=1) < 0).any(axis=1)).sum() > B // 2
+    # data near the family, so that a good share of the candidates is accepted
+    obs = ovel[0] + 0.025 * rng.standard_normal(P)
+    noise = {"std": 0.1}
+    prob = DeviceProblem(nl, 1.75, periods, obs, "normal", noise, bounds)
+    ch = DeviceChains(prob, starts, 0.02)
+    assert int((ch.init_likelihood() != 0).sum()) == 0
+    ologL = np.array([oracle.loglik(obs, v, "normal", noise) for v in ovel])
+    ost = oracle.ChainState(starts, ologL, ovel, 0.02, bounds)
+    idx = rng.integers(0, NP, (S, B)).astype(np.int32)
+    cauchy = np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5))
+    u_acc = rng.uniform(size=(S, B))
+    dev = prob.device
+    out = ch.steps(torch.tensor(idx, device=dev), torch.tensor(cauchy, device=dev),
+                   torch.tensor(u_acc, device=dev))
+    acc = np.zeros((S, B), dtype=np.uint8)
+    stat = np.zeros((S, B), dtype=np.int32)
+    lit = 0
+    for s in range(S):
+        acc[s], stat[s], ne = oracle.mh_step(ost, idx[s], cauchy[s], u_acc[s], nl, 1.75, periods,
+                                             obs, "normal", noise)
+        lit += ne
+    np.testing.assert_array_equal(out["accepted"].cpu().numpy(), acc)
+    np.testing.assert_array_equal(out["status"].cpu().numpy(), stat)
+    np.testing.assert_array_equal(ch.m.cpu().numpy(), ost.m)
+    np.testing.assert_allclose(ch.logL.cpu().numpy(), ost.logL, rtol=1e-9)
+    np.testing.assert_array_equal(ch.pred.cpu().numpy(), ost.pred)
+    assert int(ch.n_evals[0]) == lit
+    assert 0.1 < acc.mean() < 0.9
+
+
 def test_scheduled_launches_do_not_change_the_chains(oracle, candidates):
     """With the scratch of mhd_chains_t.sched the library measures what each chain costs and, from
     the second call on, runs the expensive chains with four candidates in flight and the cheap
