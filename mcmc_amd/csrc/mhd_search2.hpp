@@ -29,7 +29,10 @@
 
 namespace mhd {
 
-constexpr int MAX_REPAIRS = 3;  // then the wave-sequential search finishes the curve
+#ifndef MHD_MAX_REPAIRS
+#define MHD_MAX_REPAIRS 8
+#endif
+constexpr int MAX_REPAIRS = MHD_MAX_REPAIRS;  // then the wave-sequential search finishes the curve
 #ifndef RESYNC_PERIODS
 #define RESYNC_PERIODS 4
 #endif
