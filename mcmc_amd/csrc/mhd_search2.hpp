@@ -34,7 +34,7 @@ namespace mhd {
 #endif
 constexpr int MAX_REPAIRS = MHD_MAX_REPAIRS;  // then the wave-sequential search finishes the curve
 #ifndef RESYNC_PERIODS
-#define RESYNC_PERIODS 4
+#define RESYNC_PERIODS 10
 #endif
 constexpr int MAX_SCAN = 62;    // scan abscissae of one period the replay follows; longer scans are mostly
                                 // downward ones that end at the floor, which the wave-sequential search handles
