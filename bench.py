@@ -105,21 +105,6 @@ def cpu_baseline(periods, bounds, obs, starts, seed, budget_s=12.0):
     }
 
 
-def measured_traffic(headline, args):
-    """HBM-side bytes per call of the library (TCC FETCH_SIZE + WRITE_SIZE of all its kernels), taken
-    from the committed rocprofv3 --pmc summary of this same command; None for any other
-    configuration, or when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_v5_traffic.json")
-    if not (headline and args.chunk == 250 and args.search == 2 and args.candidates == 2):
-        return None
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return (d["fetch_kb_per_call"] + d["write_kb_per_call"]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        return None
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,9 +130,9 @@ def main():
     import torch
     import torch.distributed as dist
     from mcmc_amd.engine import DeviceChains, DeviceProblem
-    from mcmc_amd import _lib as L
-    L.check(L.lib().mhd_set_search(args.search))
-    L.check(L.lib().mhd_set_candidates(args.candidates))
+    from mcmc_amd import _lib as L, engine as E
+    E.set_default_tuning(search=args.search)
+    E.set_default_tuning(candidates=args.candidates)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -242,7 +227,8 @@ def main():
                 "chains_per_gpu": B, "n_periods": N_PERIODS, "n_layers": nl,
                 "wave": args.wave, "itype": args.itype,
                 "proposal": "cauchy", "likelihood": "normal", "rotation": args.rotation,
-                "steps_per_launch": args.chunk, "search": args.search,
+                "steps_per_call": min(args.chunk, K), "calls_timed": n_launch,
+                "search": args.search,
                 "candidates_in_flight": args.candidates, "acceptance_rate": round(acc_rate, 4),
             },
             "roofline": {
@@ -251,11 +237,14 @@ def main():
                 "peak": FP64_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-                "traffic": measured_traffic(headline, args),
-                "kernel": "mh_steps_multi_kernel" + ("<2> (with <4> beside it; a call of the library "
-                                                   "launches both twice, and launch_ms is the call)"
-                                                   if args.candidates == 2
-                                                   else "<%d>" % args.candidates),
+                # HBM bytes come from rocprofv3 --pmc passes, which this process cannot take of
+                # itself: see profiles/ for the counters of this same command
+                "traffic": None,
+                "kernel": "one call of mhd_mh_steps = " + (
+                    "%d x (schedule_kernel, then mh_steps_multi_kernel<4> and <2> side by side)"
+                    % (2 if min(args.chunk, K) >= 96 else 1) if args.candidates == 2
+                    else "mh_steps_multi_kernel<%d>" % args.candidates if args.candidates == 4
+                    else "mh_steps_kernel") + "; launch_ms is the call, by HIP events on its stream",
                 "launch_ms": launch_s * 1e3,
                 "algorithmic_evals_per_launch": lit / n_launch,
                 "executed_evals_per_launch": ex / n_launch,

@@ -7,17 +7,28 @@
  *
  * Conventions
  *   - every pointer marked "device" is caller-owned HBM (for example
- *     torch.Tensor.data_ptr()); the library allocates nothing and never frees;
+ *     torch.Tensor.data_ptr()); the library allocates no device memory and never
+ *     frees.  What it does create, once per device and kept until the process
+ *     ends, is one extra stream and two events (mhd_init);
  *   - all arrays are dense row-major, float64 unless stated;
  *   - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL
  *     is the default stream) and return 0 or a negative MHD_E* code;
  *     mhd_last_error() gives the text of the last failure on this thread;
+ *   - threads: any number of host threads may call into the library; calls of
+ *     mhd_mh_steps that use the launch schedule (mhd_chains_t.sched) are
+ *     serialised per device while they enqueue their launches.  Two calls that
+ *     work on the same chains, or on the same `sched`, must be ordered by the
+ *     caller (same stream, or events);
  *   - per-chain outcome codes (`status`) map onto the reference's counters:
  *       MHD_ST_OK       proposal evaluated
  *       MHD_ST_BOUNDS   n_bounds_err   (src/inversion/model.py:110-117)
  *       MHD_ST_PHYSICS  n_physics_err  (src/inversion/model.py:120-127)
  *       MHD_ST_NOROOT   n_fm_err, disba DispersionError (src/inversion/model.py:134-140)
  *       MHD_ST_ZERODIV  n_fm_err, ZeroDivisionError      (src/inversion/model.py:134-140)
+ *     MHD_ST_ZERODIV is reserved: numba raises ZeroDivisionError where disba
+ *     divides by a float zero, which needs a layer velocity or density of
+ *     exactly zero; the parameter bounds exclude that, no kernel of this library
+ *     returns the code, and no vector of the reference pins it.
  */
 #ifndef MCMC_AMD_H
 #define MCMC_AMD_H
@@ -29,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MHD_ABI_VERSION 2
+#define MHD_ABI_VERSION 3
 
 #define MHD_OK 0
 #define MHD_EINVAL (-22) /* bad argument (size beyond a compiled limit, NULL pointer) */
@@ -81,6 +92,15 @@ typedef struct mhd_problem {
     const double *noise_b; /* device: kappa (asym-laplace) or NULL        */
     const double *bounds;  /* device [NP,3] = lo, hi, hi-lo
                               (model_params.py:104-126); NULL for forward-only */
+    /* Tuning and testing switches without a counterpart in the reference; 0 picks
+       the default.  Every setting returns the same curves and the same chains. */
+    int32_t search;     /* root search of the forward model: 2 (default) = period-
+                           parallel (predict, replay, verify), 1 = wave-sequential */
+    int32_t candidates; /* proposals of one chain whose forward models mhd_mh_steps
+                           runs at the same time: 2 (default; with `sched` the
+                           library also picks 4 or 1 per chain), 4, or 1.  The steps
+                           are settled in order, a later candidate counting only if
+                           the earlier ones were rejected.  sample_prior uses 1. */
 } mhd_problem_t;
 
 /*
@@ -119,22 +139,22 @@ int mhd_abi_version(void);
 const char *mhd_last_error(void);
 
 /*
- * Root-search algorithm used by the forward model, process-wide: 2 (default) =
- * period-parallel search (predict, replay, verify), 1 = wave-sequential search.
- * Both return the sequential algorithm's result bit for bit; this is a tuning
- * and testing switch with no counterpart in the reference.
+ * Per-device set-up: the second stream and the two events that tie it to the
+ * caller's stream in scheduled calls of mhd_mh_steps, and the address of the
+ * library's static device scratch (mhd_mh_steps_static).  device < 0 means the
+ * current device.  Thread-safe; a second call for the same device does nothing.
+ * mhd_mh_steps calls it at its first scheduled call on a device if the caller
+ * has not; callers that must not create streams or events later (graph capture,
+ * serving loops) call it once at start-up.  No counterpart in the reference.
  */
-int mhd_set_search(int32_t algorithm);
+int mhd_init(int32_t device);
 
 /*
- * Candidates mhd_mh_steps evaluates at the same time per chain, process-wide:
- * 2 (default) = the next two proposals that pass the bounds run the forward
- * model concurrently (two waves per chain) and the steps are settled in order,
- * the second result being used only when the first candidate was rejected;
- * 1 = one candidate at a time.  The chain of states is the same either way;
- * no counterpart in the reference.  sample_prior runs always use 1.
+ * Resident workgroups per compute unit of the one-candidate MH kernel and of the
+ * forward kernel (a diagnostic of the register budget; no counterpart in the
+ * reference).
  */
-int mhd_set_candidates(int32_t n);
+int mhd_debug_occupancy(int *mh_blocks, int *fwd_blocks);
 
 /*
  * Secular (period-equation) function values, for diagnostics and parity gates:

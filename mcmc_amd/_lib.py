@@ -18,13 +18,13 @@ PHASE, GROUP = 0, 1
 NORMAL, ASYM_LAPLACE = 0, 1
 ROT_ACCUMULATE, ROT_FRAME = 1, 2
 MAX_LAYERS, MAX_PERIODS = 15, 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = (
     "mhd_abi_version",
     "mhd_last_error",
-    "mhd_set_search",
-    "mhd_set_candidates",
+    "mhd_init",
+    "mhd_debug_occupancy",
     "mhd_sched_bytes",
     "mhd_secular_batch",
     "mhd_forward_batch",
@@ -41,7 +41,7 @@ class Problem(ctypes.Structure):
         ("itype", c_int32), ("noise_dist", c_int32), ("n_noise_a", c_int32),
         ("n_noise_b", c_int32), ("vpvs", c_double), ("dc", c_double), ("dt", c_double),
         ("periods", c_void_p), ("obs", c_void_p), ("noise_a", c_void_p), ("noise_b", c_void_p),
-        ("bounds", c_void_p),
+        ("bounds", c_void_p), ("search", c_int32), ("candidates", c_int32),
     ]
 
 
@@ -81,8 +81,8 @@ def lib():
     L.mhd_abi_version.argtypes = []
     L.mhd_last_error.restype = ctypes.c_char_p
     L.mhd_last_error.argtypes = []
-    L.mhd_set_search.argtypes = [c_int32]
-    L.mhd_set_candidates.argtypes = [c_int32]
+    L.mhd_init.argtypes = [c_int32]
+    L.mhd_debug_occupancy.argtypes = [c_void_p, c_void_p]
     L.mhd_sched_bytes.argtypes = [c_int32]
     L.mhd_sched_bytes.restype = ctypes.c_size_t
     L.mhd_secular_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,

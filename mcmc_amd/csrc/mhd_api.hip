@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "mhd_device.hpp"
 #include "mhd_search2.hpp"
@@ -13,12 +14,6 @@ using namespace mhd;
 namespace {
 
 thread_local char g_err[256] = "";
-
-// 2 = period-parallel predicted search (default), 1 = wave-sequential search
-int g_search = 2;
-
-// candidates evaluated at the same time per chain: 2 (default) or 1
-int g_candidates = 2;
 
 int fail(int code, const char* what)
 {
@@ -44,6 +39,10 @@ int check_problem(const mhd_problem_t* p, bool need_data)
     if (p->mode < 0 || p->mode > 64) return fail(MHD_EINVAL, "bad mode");
     if (!(p->dc > 0.0) && !(p->dc < 0.0)) return fail(MHD_EINVAL, "dc must be non-zero");
     if (!p->periods) return fail(MHD_EINVAL, "periods is NULL");
+    if (p->search != 0 && p->search != 1 && p->search != 2)
+        return fail(MHD_EINVAL, "search must be 0 (default), 1 or 2");
+    if (p->candidates != 0 && p->candidates != 1 && p->candidates != 2 && p->candidates != 4)
+        return fail(MHD_EINVAL, "candidates must be 0 (default), 1, 2 or 4");
     if (need_data) {
         if (!p->obs || !p->noise_a || !p->bounds)
             return fail(MHD_EINVAL, "obs / noise_a / bounds is NULL");
@@ -933,35 +932,57 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
 // ---------------------------------------------------------------------------
 namespace {
 
-// A second stream per device for the two-candidate kernel of a scheduled launch, with the
-// events that tie it to the caller's stream.  Created at the first use, kept until the process
-// ends.
-struct SideStream {
+// What the library keeps per device, made by mhd_init() and kept until the process ends: a
+// second stream for the two-candidate kernel of a scheduled call with the events that tie it to
+// the caller's stream, and the number of compute units.  `mu` serialises the set-up and the
+// fork / launch / join sequence of scheduled calls (the events are shared).
+struct DeviceState {
+    std::mutex mu;
+    bool ready = false;
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    bool ready = false;
+    int cus = 0;
 };
-SideStream g_side[32];
+constexpr int MAX_DEVICES = 64;
+DeviceState g_dev[MAX_DEVICES];
 
-SideStream* side_stream()
+// The state of `device` (< 0: the current one), set up if it is not yet and `create` allows it.
+DeviceState* device_state(int device, bool create)
 {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess || dev < 0 || dev >= 32) {
+    hipError_t e = hipSuccess;
+    int cur = 0;
+    e = hipGetDevice(&cur);
+    if (e != hipSuccess) {
         hip_fail(e, "hipGetDevice");
         return nullptr;
     }
-    SideStream& sd = g_side[dev];
-    if (!sd.ready) {
-        e = hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming);
-        if (e != hipSuccess) {
-            hip_fail(e, "side stream");
-            return nullptr;
-        }
-        sd.ready = true;
+    if (device < 0) device = cur;
+    if (device >= MAX_DEVICES) {
+        fail(MHD_EINVAL, "device index beyond the library's table");
+        return nullptr;
     }
+    DeviceState& sd = g_dev[device];
+    std::lock_guard<std::mutex> lock(sd.mu);
+    if (sd.ready) return &sd;
+    if (!create) {
+        fail(MHD_EINVAL, "mhd_init() has not been called for this device");
+        return nullptr;
+    }
+    if (device != cur) e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipDeviceGetAttribute(&sd.cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (device != cur) {
+        const hipError_t e2 = hipSetDevice(cur);
+        if (e == hipSuccess) e = e2;
+    }
+    if (e != hipSuccess) {
+        hip_fail(e, "mhd_init");
+        return nullptr;
+    }
+    sd.ready = true;
     return &sd;
 }
 
@@ -1033,19 +1054,7 @@ int mhd_debug_profile_hi(unsigned long long* out16)
 }
 #endif
 
-int mhd_set_search(int32_t algorithm)
-{
-    if (algorithm != 1 && algorithm != 2) return fail(MHD_EINVAL, "algorithm must be 1 or 2");
-    g_search = algorithm;
-    return MHD_OK;
-}
-
-int mhd_set_candidates(int32_t n)
-{
-    if (n != 1 && n != 2 && n != 4) return fail(MHD_EINVAL, "candidates must be 1, 2 or 4");
-    g_candidates = n;
-    return MHD_OK;
-}
+int mhd_init(int32_t device) { return device_state(device, true) ? MHD_OK : MHD_EHIP; }
 
 const char* mhd_last_error(void) { return g_err; }
 
@@ -1071,7 +1080,7 @@ int mhd_forward_batch(const mhd_problem_t* prob, const double* params, int32_t B
     if (B == 0) return MHD_OK;  // (an empty batch may come with NULL arrays)
     if (!params || !vel || !status) return fail(MHD_EINVAL, "NULL argument");
     hipLaunchKernelGGL(forward_kernel, dim3(B), dim3(64), WAVE_LDS_BYTES, (hipStream_t)stream, *prob, params, B,
-                       vel, status, (unsigned long long*)n_evals, g_search);
+                       vel, status, (unsigned long long*)n_evals, prob->search ? prob->search : 2);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_forward_batch launch");
 }
@@ -1100,68 +1109,89 @@ static int check_chains(const mhd_chains_t* ch, int rotate)
     return MHD_OK;
 }
 
+// mhd_mh_steps for checked arguments.  create_state: whether the per-device state may be set up
+// here when mhd_init() has not been called for the device.
+static int mh_steps_launch(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
+                           int32_t n_steps, const int32_t* idx, const double* cauchy,
+                           const double* u_acc, double T, int32_t rotate, int32_t sample_prior,
+                           uint8_t* accepted, int32_t* status, int32_t hist_every, double* hist_m,
+                           double* hist_logL, double* hist_pred, uint64_t* n_evals,
+                           hipStream_t s, bool create_state)
+{
+    unsigned long long* ne = (unsigned long long*)n_evals;
+    const int search = prob->search ? prob->search : 2;
+    const int candidates = prob->candidates ? prob->candidates : 2;
+    if (candidates == 2 && !sample_prior && chains->sched && B >= 64 && B <= SCHED_MAX_CHAINS) {
+        // the most expensive chains with four candidates (first, so that they are resident when
+        // the others fill the GPU), the others beside them on a second stream
+        DeviceState* sd = device_state(-1, create_state);
+        if (!sd) return MHD_EHIP;
+        const int slots = sd->cus * 8;  // two waves of these kernels per SIMD
+        // (a short call is one launch: a deadline and a second launch cost more than they even out)
+        const int phases = n_steps >= SCHED_PHASES_MIN_STEPS ? SCHED_PHASES : 1;
+        // the events are shared by the callers of this device: one call enqueues at a time
+        std::lock_guard<std::mutex> lock(sd->mu);
+        for (int phase = 0; phase < phases; ++phase) {
+            hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, chains->sched, B,
+                               n_steps, phase, phases, slots);
+            hipError_t e = hipEventRecord(sd->fork, s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(sd->stream, sd->fork, 0);
+            if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps fork");
+            hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(sched_cap4(B, phase)), dim3(256),
+                               4 * WAVE_LDS_BYTES, s, *prob, *chains, B, n_steps, idx, cauchy,
+                               u_acc, T, rotate, accepted, status, hist_every, hist_m, hist_logL,
+                               hist_pred, ne, search, 1);
+            hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES,
+                               sd->stream, *prob, *chains, B, n_steps, idx, cauchy, u_acc, T,
+                               rotate, accepted, status, hist_every, hist_m, hist_logL, hist_pred,
+                               ne, search, 1);
+            e = hipEventRecord(sd->join, sd->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, sd->join, 0);
+            if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps join");
+        }
+    } else if (candidates == 2 && !sample_prior) {
+        hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES, s,
+                           *prob, *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, accepted,
+                           status, hist_every, hist_m, hist_logL, hist_pred, ne, search, 0);
+    } else if (candidates == 4 && !sample_prior) {
+        hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(B), dim3(256), 4 * WAVE_LDS_BYTES, s,
+                           *prob, *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, accepted,
+                           status, hist_every, hist_m, hist_logL, hist_pred, ne, search, 0);
+    } else {
+        hipLaunchKernelGGL(mh_steps_kernel, dim3(B), dim3(64), WAVE_LDS_BYTES, s, *prob, *chains,
+                           B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior, accepted,
+                           status, hist_every, hist_m, hist_logL, hist_pred, ne, search);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_mh_steps launch");
+}
+
+// 0: go on; 1: nothing to do; < 0: refused
+static int mh_steps_check(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
+                          int32_t n_steps, const int32_t* idx, const double* cauchy,
+                          const double* u_acc, double T, int32_t rotate, int32_t hist_every)
+{
+    if (int rc = check_problem(prob, true)) return rc;
+    if (int rc = check_chains(chains, rotate)) return rc;
+    if (B < 0 || n_steps < 0 || hist_every < 0) return fail(MHD_EINVAL, "negative size");
+    if (!(T > 0.0)) return fail(MHD_EINVAL, "T must be positive");
+    if (B == 0 || n_steps == 0) return 1;  // (no steps may come with NULL draw arrays)
+    if (!idx || !cauchy || !u_acc) return fail(MHD_EINVAL, "draw array is NULL");
+    return 0;
+}
+
 int mhd_mh_steps(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
                  int32_t n_steps, const int32_t* idx, const double* cauchy, const double* u_acc,
                  double T, int32_t rotate, int32_t sample_prior, uint8_t* accepted,
                  int32_t* status, int32_t hist_every, double* hist_m, double* hist_logL,
                  double* hist_pred, uint64_t* n_evals, void* stream)
 {
-    if (int rc = check_problem(prob, true)) return rc;
-    if (int rc = check_chains(chains, rotate)) return rc;
-    if (B < 0 || n_steps < 0 || hist_every < 0) return fail(MHD_EINVAL, "negative size");
-    if (!(T > 0.0)) return fail(MHD_EINVAL, "T must be positive");
-    if (B == 0 || n_steps == 0) return MHD_OK;  // (no steps may come with NULL draw arrays)
-    if (!idx || !cauchy || !u_acc) return fail(MHD_EINVAL, "draw array is NULL");
-    hipStream_t s = (hipStream_t)stream;
-    unsigned long long* ne = (unsigned long long*)n_evals;
-    if (g_candidates == 2 && !sample_prior && chains->sched && B >= 64 &&
-        B <= SCHED_MAX_CHAINS) {
-        // the most expensive chains with four candidates (first, so that they are resident when
-        // the others fill the GPU), the others beside them on a second stream
-        SideStream* side = side_stream();
-        if (!side) return MHD_EHIP;
-        int dev = 0, cus = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess)
-            e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps device");
-        const int slots = cus * 8;  // two waves of these kernels per SIMD
-        // (a short call is one launch: a deadline and a second launch cost more than they even out)
-        const int phases = n_steps >= SCHED_PHASES_MIN_STEPS ? SCHED_PHASES : 1;
-        for (int phase = 0; phase < phases; ++phase) {
-            hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, chains->sched, B,
-                               n_steps, phase, phases, slots);
-            e = hipEventRecord(side->fork, s);
-            if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
-            if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps fork");
-            hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(sched_cap4(B, phase)), dim3(256),
-                               4 * WAVE_LDS_BYTES, s, *prob, *chains, B, n_steps, idx, cauchy,
-                               u_acc, T, rotate, accepted, status, hist_every, hist_m, hist_logL,
-                               hist_pred, ne, g_search, 1);
-            hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES,
-                               side->stream, *prob, *chains, B, n_steps, idx, cauchy, u_acc, T,
-                               rotate, accepted, status, hist_every, hist_m, hist_logL, hist_pred,
-                               ne, g_search, 1);
-            e = hipEventRecord(side->join, side->stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(s, side->join, 0);
-            if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps join");
-        }
-    } else if (g_candidates == 2 && !sample_prior) {
-        hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES, s,
-                           *prob, *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, accepted,
-                           status, hist_every, hist_m, hist_logL, hist_pred, ne, g_search, 0);
-    } else if (g_candidates == 4 && !sample_prior) {
-        hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(B), dim3(256), 4 * WAVE_LDS_BYTES, s,
-                           *prob, *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, accepted,
-                           status, hist_every, hist_m, hist_logL, hist_pred, ne, g_search, 0);
-    } else {
-        hipLaunchKernelGGL(mh_steps_kernel, dim3(B), dim3(64), WAVE_LDS_BYTES, (hipStream_t)stream, *prob,
-                           *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior,
-                           accepted, status, hist_every, hist_m, hist_logL, hist_pred,
-                           (unsigned long long*)n_evals, g_search);
-    }
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_mh_steps launch");
+    const int rc = mh_steps_check(prob, chains, B, n_steps, idx, cauchy, u_acc, T, rotate,
+                                  hist_every);
+    if (rc) return rc < 0 ? rc : MHD_OK;
+    return mh_steps_launch(prob, chains, B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior,
+                           accepted, status, hist_every, hist_m, hist_logL, hist_pred, n_evals,
+                           (hipStream_t)stream, true);
 }
 
 int mhd_cov_accumulate(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,

@@ -1251,8 +1251,15 @@ __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode,
 {
     // (hint is never tested against null: a null test of a pointer into LDS trips the compiler;
     // without a hint the callers pass any valid pointer and use_hint = false)
-    if (mode != 0)
+    if (mode != 0) {
+        // the callers read these after every forward: higher modes use no predictor
+        if ((threadIdx.x & 63) == 0) {
+            g_PS.trouble = 0;
+            g_PS.hinted = 0;
+        }
+        wave_sync();
         return forward_wave(T, wave, mode, itype, t, P, dc, dt, vel, scratch, cnt);
+    }
     if (itype == MHD_PHASE) {
         const int st = phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt, stepwise, hint, use_hint);
 #ifdef MHD_PROFILE

@@ -11,8 +11,22 @@ import torch
 from . import _lib as L
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# Defaults of the two tuning switches of struct mhd_problem (0 = the library's default) for
+# problems that do not set their own; read at every call, so tests can flip them around a call.
+_TUNING = {"search": 0, "candidates": 0}
+
+
+def set_default_tuning(search=None, candidates=None):
+    """search: 2 period-parallel, 1 wave-sequential; candidates in flight per chain: 4, 2, 1;
+    0 restores the library's default.  Every setting returns the same curves and chains."""
+    if search is not None:
+        _TUNING["search"] = int(search)
+    if candidates is not None:
+        _TUNING["candidates"] = int(candidates)
 
 
 def _ptr(t):
@@ -43,7 +57,7 @@ class DeviceProblem:
 
     def __init__(self, n_layers, vpvs, periods, obs=None, noise_dist="normal", noise_params=None,
                  bounds=None, wave="rayleigh", mode=0, itype="phase", dc=0.005, dt=0.025,
-                 device=None):
+                 device=None, search=0, candidates=0):
         L.lib()
         if not torch.cuda.is_available():
             raise L.MhdError("no GPU visible: the hot path has no CPU fallback")
@@ -51,6 +65,9 @@ class DeviceProblem:
                                    f"cuda:{torch.cuda.current_device()}")
         self.n_layers = int(n_layers)
         self.NP = 2 * self.n_layers + 1
+        self.search, self.candidates = int(search), int(candidates)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().mhd_init(self.device.index))
         periods = np.ascontiguousarray(periods, dtype=np.float64)
         self.P = len(periods)
         if self.n_layers < 1 or self.n_layers > L.MAX_LAYERS:
@@ -82,6 +99,12 @@ class DeviceProblem:
             noise_b=None if self.noise_b is None else self.noise_b.data_ptr(),
             bounds=None if self.bounds is None else self.bounds.data_ptr())
 
+    def cref(self):
+        """The struct for a call, with the tuning switches as they stand now."""
+        self.c.search = self.search or _TUNING["search"]
+        self.c.candidates = self.candidates or _TUNING["candidates"]
+        return ctypes.byref(self.c)
+
     # -- forward_model for a batch (src/inversion/model_params.py:178-209) --
     def forward(self, params, n_evals=None):
         """params [B,NP] device tensor -> (vel [B,P], status [B] int32)."""
@@ -90,17 +113,19 @@ class DeviceProblem:
         assert params.shape[1] == self.NP and params.dtype == torch.float64
         vel = torch.empty((B, self.P), dtype=torch.float64, device=self.device)
         status = torch.empty(B, dtype=torch.int32, device=self.device)
-        L.check(L.lib().mhd_forward_batch(ctypes.byref(self.c), _ptr(params), B, _ptr(vel),
-                                          _ptr(status), _ptr(n_evals), _stream()))
+        with torch.cuda.device(self.device):
+            L.check(L.lib().mhd_forward_batch(self.cref(), _ptr(params), B, _ptr(vel),
+                                              _ptr(status), _ptr(n_evals), _stream(self.device)))
         return vel, status
 
     def secular(self, params, chain, period, c):
         params = params.contiguous()
         N = chain.numel()
         delta = torch.empty(N, dtype=torch.float64, device=self.device)
-        L.check(L.lib().mhd_secular_batch(ctypes.byref(self.c), _ptr(params), params.shape[0],
-                                          _ptr(chain), _ptr(period), _ptr(c), N, _ptr(delta),
-                                          _stream()))
+        with torch.cuda.device(self.device):
+            L.check(L.lib().mhd_secular_batch(self.cref(), _ptr(params), params.shape[0],
+                                              _ptr(chain), _ptr(period), _ptr(c), N, _ptr(delta),
+                                              _stream(self.device)))
         return delta
 
     # -- Model.get_likelihood for a batch (src/inversion/model.py:420-447) --
@@ -108,8 +133,9 @@ class DeviceProblem:
         pred = pred.contiguous()
         B = pred.shape[0]
         out = torch.empty(B, dtype=torch.float64, device=self.device)
-        L.check(L.lib().mhd_loglik_batch(ctypes.byref(self.c), _ptr(pred), B, _ptr(out),
-                                         _stream()))
+        with torch.cuda.device(self.device):
+            L.check(L.lib().mhd_loglik_batch(self.cref(), _ptr(pred), B, _ptr(out),
+                                             _stream(self.device)))
         return out
 
 
@@ -188,14 +214,16 @@ class DeviceChains:
                                  device=dev)
                 out["hist_pred"] = hp
         ch = self.struct()
-        L.check(L.lib().mhd_mh_steps(
-            ctypes.byref(self.prob.c), ctypes.byref(ch), B, S, _ptr(idx), _ptr(cauchy),
-            _ptr(u_acc), float(T), int(rotate), int(bool(sample_prior)), _ptr(acc),
-            _ptr(st), int(hist_every), _ptr(hm), _ptr(hl), _ptr(hp), _ptr(self.n_evals),
-            _stream()))
+        with torch.cuda.device(dev):
+            L.check(L.lib().mhd_mh_steps(
+                self.prob.cref(), ctypes.byref(ch), B, S, _ptr(idx), _ptr(cauchy),
+                _ptr(u_acc), float(T), int(rotate), int(bool(sample_prior)), _ptr(acc),
+                _ptr(st), int(hist_every), _ptr(hm), _ptr(hl), _ptr(hp), _ptr(self.n_evals),
+                _stream(dev)))
         return out
 
     def cov_accumulate(self):
         ch = self.struct()
-        L.check(L.lib().mhd_cov_accumulate(ctypes.byref(self.prob.c), ctypes.byref(ch), self.B,
-                                           _stream()))
+        with torch.cuda.device(self.prob.device):
+            L.check(L.lib().mhd_cov_accumulate(self.prob.cref(), ctypes.byref(ch), self.B,
+                                               _stream(self.prob.device)))

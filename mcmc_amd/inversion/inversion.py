@@ -29,7 +29,6 @@ the per-chain logL per tempering sweep, after which every rank takes the same
 swap decisions from the same uniforms and updates the betas it owns.
 """
 import os
-import time
 
 import numpy as np
 
@@ -76,7 +75,9 @@ class Inversion:
         self.swap_acc = 0
         self.swap_prop = 0
         self.out_dir = out_dir
-        self.out_filename = str(int(time.time())) if not out_filename else out_filename
+        # results are written only when the caller names a file (the reference makes up a name
+        # from the clock, src/inversion/inversion.py:62-66; with several ranks those would differ)
+        self.out_filename = out_filename if out_filename else None
         self.initialize_chains(model_params, noise_dist, noise_params, n_cov_chunk,
                                individual_acceptance, beta_spacing_factor, set_starting_model)
         if out_filename is not None and self.rank == 0:
@@ -139,10 +140,15 @@ class Inversion:
 
     # ------------------------------------------------------------------ output
     def _path(self, kind, chunk=None):
+        """input-<name>.npz, results-<name>-<chunk>.npz; with several ranks every rank writes the
+        records of the chains it owns: results-<name>-r<rank>-<chunk>.npz."""
         name = self.out_filename.split("/")[-1]
         base = os.path.join(self.out_dir, self.out_filename)
         base = base[: len(base) - len(name)] + kind + "-" + name
-        return base + (".npz" if chunk is None else f"-{chunk:05d}.npz")
+        if chunk is None:
+            return base + ".npz"
+        rank = f"-r{self.rank}" if self.world > 1 else ""
+        return base + f"{rank}-{chunk:05d}.npz"
 
     def define_input_dataset(self, data, model_params, noise_dist, noise_params):
         """input-<name>.npz with the fields of src/inversion/inversion.py:93-132."""

@@ -46,26 +46,6 @@ class DispersionCurveParams(ModelParams):
         }
         self._problems = {}
 
-    def get_model_params_dict(self):
-        """src/inversion/model_params.py:57-92."""
-        d = {
-            "coords": {
-                "n_model_params": {"dims": ["n_model_params"],
-                                   "data": np.arange(self.n_model_params)},
-                "n_bounds": {"dims": ["n_bounds"], "data": np.arange(3)},
-            },
-            "data_vars": {
-                "param_bounds": {"dims": ["n_model_params", "n_bounds"],
-                                 "data": self.assemble_param_bounds()},
-                "proposal_width": {"dims": ["n_model_params"],
-                                   "data": self.assemble_proposal_width()},
-            },
-            "attrs": {"n_layers": self.n_layers, "vpvs_ratio": self.vpvs_ratio},
-        }
-        for key, val in self.params_info.items():
-            d["data_vars"][key + "_inds"] = {"dims": ["n_model_params"], "data": val["inds"]}
-        return d
-
     def get_vel_p(self, vel_s):
         return vel_s * self.vpvs_ratio
 

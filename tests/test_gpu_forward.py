@@ -56,7 +56,7 @@ def test_forward_low_velocity_zones(torch_cuda, oracle, search):
     its curve jumps downwards between periods: both device searches must land on the same lattice
     points as the sequential algorithm, jumps included."""
     torch = torch_cuda
-    from mcmc_amd import _lib as L
+    from mcmc_amd import _lib as L, engine as E
     from mcmc_amd.engine import DeviceProblem
     rng = np.random.default_rng(166)
     nl, P, B = 6, 40, 512
@@ -68,13 +68,13 @@ def test_forward_low_velocity_zones(torch_cuda, oracle, search):
     params[1:, nl:] *= 1.0 + 0.10 * rng.standard_normal((B - 1, nl + 1))
     params[:, :nl] = np.sort(params[:, :nl], axis=1)
     params[:, nl:] = np.clip(params[:, nl:], 0.1, 2.0)
-    L.check(L.lib().mhd_set_search(search))
+    E.set_default_tuning(search=search)
     try:
         prob = DeviceProblem(nl, 1.75, periods)
         ne = torch.zeros(2, dtype=torch.int64, device=prob.device)
         vel, status = prob.forward(torch.tensor(params, device=prob.device), n_evals=ne)
     finally:
-        L.check(L.lib().mhd_set_search(2))
+        E.set_default_tuning(search=0)
     ost, ovel, one = oracle.forward_batch(params, nl, 1.75, periods, nthreads=8)
     vel, status = vel.cpu().numpy(), status.cpu().numpy()
     assert (status == ost).all()

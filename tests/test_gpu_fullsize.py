@@ -24,16 +24,16 @@ def _setup(seed):
 
 
 def test_forward_both_searches_agree_at_full_size():
-    from mcmc_amd import _lib as L
+    from mcmc_amd import _lib as L, engine as E
     _, _, _, prob0, cand = _setup(11)
     out = {}
     import torch
     for alg in (2, 1):
-        L.check(L.lib().mhd_set_search(alg))
+        E.set_default_tuning(search=alg)
         ne = torch.zeros(2, dtype=torch.int64, device=prob0.device)
         vel, st = prob0.forward(cand, n_evals=ne)
         out[alg] = (vel.clone(), st.clone(), int(ne[0]))
-    L.check(L.lib().mhd_set_search(2))
+    E.set_default_tuning(search=0)
     assert out[1][2] == out[2][2] > 0                    # same sequential-algorithm evaluation count
     assert bool((out[1][1] == out[2][1]).all())
     assert bool((out[1][0] == out[2][0]).all())          # bit-identical curves, failures included
@@ -45,7 +45,7 @@ def test_forward_both_searches_agree_at_full_size():
 
 def test_chains_every_way_of_running_agrees_at_full_size():
     import torch
-    from mcmc_amd import _lib as L
+    from mcmc_amd import _lib as L, engine as E
     from mcmc_amd.engine import DeviceChains, DeviceProblem
     rng, periods, bounds, prob0, cand = _setup(12)
     _, st = prob0.forward(cand)
@@ -61,8 +61,8 @@ def test_chains_every_way_of_running_agrees_at_full_size():
     results = []
     # scheduled two/four/one candidates; plain two candidates; one candidate with either search
     for cands, search, sched in ((2, 2, True), (2, 2, False), (1, 2, False), (1, 1, False)):
-        L.check(L.lib().mhd_set_candidates(cands))
-        L.check(L.lib().mhd_set_search(search))
+        E.set_default_tuning(candidates=cands)
+        E.set_default_tuning(search=search)
         ch = DeviceChains(prob, starts, 0.05)
         if not sched:
             ch.sched = None
@@ -73,8 +73,8 @@ def test_chains_every_way_of_running_agrees_at_full_size():
             acc.append(out["accepted"])
         results.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(),
                         torch.cat(acc), int(ch.n_evals[0])))
-    L.check(L.lib().mhd_set_candidates(2))
-    L.check(L.lib().mhd_set_search(2))
+    E.set_default_tuning(candidates=0)
+    E.set_default_tuning(search=0)
     ref = results[0]
     for other in results[1:]:
         for x, y in zip(ref[:5], other[:5]):

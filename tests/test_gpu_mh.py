@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=[4, 2, 1], ids=["four", "two", "one"])
 def candidates(request):
     """Every test runs with four, two (the default) and one candidate per chain in flight."""
-    from mcmc_amd import _lib as L
-    L.check(L.lib().mhd_set_candidates(request.param))
+    from mcmc_amd import _lib as L, engine as E
+    E.set_default_tuning(candidates=request.param)
     yield request.param
-    L.check(L.lib().mhd_set_candidates(2))
+    E.set_default_tuning(candidates=0)
 
 
 def _noise(g):

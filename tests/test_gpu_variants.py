@@ -20,19 +20,19 @@ def _draws(rng, n, n_layers):
 @pytest.mark.parametrize("search", [2, 1])
 def test_forward_variants_match_the_oracle(oracle, wave, mode, itype, search):
     import torch
-    from mcmc_amd import _lib as L
+    from mcmc_amd import _lib as L, engine as E
     from mcmc_amd.engine import DeviceProblem
     rng = np.random.default_rng(41 + mode)
     nl, P, B = 4, 30, 192
     periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
     params = _draws(rng, B, nl)
-    L.check(L.lib().mhd_set_search(search))
+    E.set_default_tuning(search=search)
     try:
         prob = DeviceProblem(nl, 1.75, periods, wave=wave, mode=mode, itype=itype)
         ne = torch.zeros(2, dtype=torch.int64, device=prob.device)
         vel, st = prob.forward(torch.tensor(params, device=prob.device), n_evals=ne)
     finally:
-        L.check(L.lib().mhd_set_search(2))
+        E.set_default_tuning(search=0)
     ost, ovel, one = oracle.forward_batch(params, nl, 1.75, periods, wave=int(wave == "love"),
                                           mode=mode, itype=int(itype == "group"), nthreads=8)
     vel, st = vel.cpu().numpy(), st.cpu().numpy()
