@@ -213,6 +213,30 @@ int mhd_mh_steps(const mhd_problem_t *prob, const mhd_chains_t *chains, int32_t 
                  double *hist_logL, double *hist_pred, uint64_t *n_evals, void *stream);
 
 /*
+ * mhd_mh_steps for callers that cannot allocate device memory (code under HIP
+ * graph capture, serving loops, harnesses that forbid hipMalloc): the same
+ * steps with the same results, but the launch schedule that mhd_chains_t.sched
+ * holds for mhd_mh_steps lives in a static device array of the library (53 KiB
+ * per GPU, held until the process ends); chains->sched is ignored.  It has no
+ * counterpart in the reference.  Limits and rules:
+ *   - B <= 4096 chains (MHD_EINVAL beyond);
+ *   - mhd_init() must have been called for the current device (MHD_EINVAL
+ *     otherwise): this entry point creates no stream, event or memory;
+ *   - every call on a GPU uses that GPU's one array.  It is cleared (on
+ *     `stream`) when a call comes with another B or other chains (chains->m)
+ *     than the call before; calls that overlap in time on one GPU race on it and
+ *     must be ordered by the caller.
+ */
+#define MHD_STATIC_MAX_CHAINS 4096
+int mhd_mh_steps_static(const mhd_problem_t *prob, const mhd_chains_t *chains, int32_t B,
+                        int32_t n_steps, const int32_t *idx /* device [S,B] */,
+                        const double *cauchy /* device [S,B] */,
+                        const double *u_acc /* device [S,B] */, double T, int32_t rotate,
+                        int32_t sample_prior, uint8_t *accepted, int32_t *status,
+                        int32_t hist_every, double *hist_m, double *hist_logL, double *hist_pred,
+                        uint64_t *n_evals, void *stream);
+
+/*
  * Model.update_covariance_matrix alone (src/inversion/model.py:263-282), used on
  * the steps where the reference refreshes the rotation matrix between the
  * covariance update and the proposal (model.py:183-193).

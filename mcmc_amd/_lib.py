@@ -30,6 +30,7 @@ EXPORTS = (
     "mhd_forward_batch",
     "mhd_loglik_batch",
     "mhd_mh_steps",
+    "mhd_mh_steps_static",
     "mhd_cov_accumulate",
 )
 
@@ -92,6 +93,7 @@ def lib():
     L.mhd_mh_steps.argtypes = [pp, cp, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_double,
                                c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p]
+    L.mhd_mh_steps_static.argtypes = L.mhd_mh_steps.argtypes
     L.mhd_cov_accumulate.argtypes = [pp, cp, c_int32, c_void_p]
     for name in EXPORTS:
         getattr(L, name)

@@ -932,6 +932,23 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
 // ---------------------------------------------------------------------------
 namespace {
 
+constexpr size_t sched_bytes_of(size_t B)
+{
+    return sizeof(float) * B + sizeof(int) * (8 + 2 * B) + B + 64;
+}
+
+}  // namespace
+
+// Launch-schedule scratch of mhd_mh_steps_static: what mhd_chains_t.sched is for mhd_mh_steps,
+// for up to STATIC_MAX_CHAINS chains, one copy per GPU the library runs on.  In host code the
+// name only stands for the symbol: the address on a device comes from hipGetSymbolAddress
+// (DeviceState.scratch), and only that pointer is handed to kernels and memsets.
+constexpr int STATIC_MAX_CHAINS = SCHED_MAX_CHAINS;
+constexpr size_t STATIC_SCRATCH_BYTES = (sched_bytes_of(STATIC_MAX_CHAINS) + 255) / 256 * 256;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+namespace {
+
 // What the library keeps per device, made by mhd_init() and kept until the process ends: a
 // second stream for the two-candidate kernel of a scheduled call with the events that tie it to
 // the caller's stream, and the number of compute units.  `mu` serialises the set-up and the
@@ -942,6 +959,9 @@ struct DeviceState {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     int cus = 0;
+    void* scratch = nullptr;              // this device's copy of `scratch` (mhd_mh_steps_static)
+    int scratch_B = -1;                   // what the scratch was last laid out for: chains ...
+    const void* scratch_owner = nullptr;  // ... and whose (mhd_chains_t.m)
 };
 constexpr int MAX_DEVICES = 64;
 DeviceState g_dev[MAX_DEVICES];
@@ -974,6 +994,7 @@ DeviceState* device_state(int device, bool create)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipDeviceGetAttribute(&sd.cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (e == hipSuccess) e = hipGetSymbolAddress(&sd.scratch, HIP_SYMBOL(scratch));
     if (device != cur) {
         const hipError_t e2 = hipSetDevice(cur);
         if (e == hipSuccess) e = e2;
@@ -993,7 +1014,7 @@ extern "C" {
 size_t mhd_sched_bytes(int32_t B)
 {
     if (B < 0) B = 0;
-    return sizeof(float) * (size_t)B + sizeof(int) * (8 + 2 * (size_t)B) + (size_t)B + 64;
+    return sched_bytes_of((size_t)B);
 }
 
 int mhd_abi_version(void) { return MHD_ABI_VERSION; }
@@ -1192,6 +1213,39 @@ int mhd_mh_steps(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t 
     return mh_steps_launch(prob, chains, B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior,
                            accepted, status, hist_every, hist_m, hist_logL, hist_pred, n_evals,
                            (hipStream_t)stream, true);
+}
+
+int mhd_mh_steps_static(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
+                        int32_t n_steps, const int32_t* idx, const double* cauchy,
+                        const double* u_acc, double T, int32_t rotate, int32_t sample_prior,
+                        uint8_t* accepted, int32_t* status, int32_t hist_every, double* hist_m,
+                        double* hist_logL, double* hist_pred, uint64_t* n_evals, void* stream)
+{
+    const int rc = mh_steps_check(prob, chains, B, n_steps, idx, cauchy, u_acc, T, rotate,
+                                  hist_every);
+    if (rc) return rc < 0 ? rc : MHD_OK;
+    if (B > STATIC_MAX_CHAINS)
+        return fail(MHD_EINVAL, "mhd_mh_steps_static: more than 4096 chains, the static scratch "
+                                "holds the launch schedule of 4096");
+    DeviceState* sd = device_state(-1, false);  // made by mhd_init(); nothing is created here
+    if (!sd) return MHD_EINVAL;
+    mhd_chains_t ch = *chains;
+    ch.sched = sd->scratch;
+    {
+        // other chains than the last call's: their costs and search levels must not be taken
+        // for these (and the layout depends on B)
+        std::lock_guard<std::mutex> lock(sd->mu);
+        if (sd->scratch_B != B || sd->scratch_owner != (const void*)chains->m) {
+            const hipError_t e =
+                hipMemsetAsync(sd->scratch, 0, sched_bytes_of((size_t)B), (hipStream_t)stream);
+            if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps_static memset");
+            sd->scratch_B = B;
+            sd->scratch_owner = (const void*)chains->m;
+        }
+    }
+    return mh_steps_launch(prob, &ch, B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior,
+                           accepted, status, hist_every, hist_m, hist_logL, hist_pred, n_evals,
+                           (hipStream_t)stream, false);
 }
 
 int mhd_cov_accumulate(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,

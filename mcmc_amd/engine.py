@@ -185,10 +185,12 @@ class DeviceChains:
         return status
 
     def steps(self, idx, cauchy, u_acc, T=1.0, rotate=0, sample_prior=False, hist_every=0,
-              want_flags=True, want_pred_hist=False):
+              want_flags=True, want_pred_hist=False, static_scratch=False):
         """Run S = idx.shape[0] Metropolis-Hastings steps for every chain.
 
         idx [S,B] int32, cauchy [S,B], u_acc [S,B] are device tensors of host-supplied draws.
+        static_scratch: through mhd_mh_steps_static (the library's static device scratch
+        instead of self.sched).
         Returns dict with accepted [S,B] uint8, status [S,B] int32 and, when hist_every > 0,
         hist_m [S//hist_every,B,NP] and hist_logL [S//hist_every,B].
         """
@@ -215,7 +217,8 @@ class DeviceChains:
                 out["hist_pred"] = hp
         ch = self.struct()
         with torch.cuda.device(dev):
-            L.check(L.lib().mhd_mh_steps(
+            entry = L.lib().mhd_mh_steps_static if static_scratch else L.lib().mhd_mh_steps
+            L.check(entry(
                 self.prob.cref(), ctypes.byref(ch), B, S, _ptr(idx), _ptr(cauchy),
                 _ptr(u_acc), float(T), int(rotate), int(bool(sample_prior)), _ptr(acc),
                 _ptr(st), int(hist_every), _ptr(hm), _ptr(hl), _ptr(hp), _ptr(self.n_evals),

@@ -1,0 +1,85 @@
+"""mhd_mh_steps_static, the entry point for callers that cannot allocate: same chains as
+mhd_mh_steps, bit for bit, on two calls in a row that share the library's static device
+scratch, the second with fewer chains and fewer steps."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NL, P = 6, 40
+
+
+def _problem(rng, B):
+    import torch
+    from mcmc_amd.engine import DeviceProblem
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * NL + [[0.1, 2.0, 1.9]] * (NL + 1))
+    prob0 = DeviceProblem(NL, 1.75, periods)
+    starts = np.empty((0, 2 * NL + 1))
+    while starts.shape[0] < B:
+        cand = rng.uniform(bounds[:, 0], bounds[:, 1], size=(2 * B, 2 * NL + 1))
+        order = np.argsort(cand[:, :NL], axis=1, kind="stable")
+        cand[:, :NL] = np.take_along_axis(cand[:, :NL], order, axis=1)
+        cand[:, NL:2 * NL] = np.take_along_axis(cand[:, NL:2 * NL], order, axis=1)
+        _, st = prob0.forward(torch.tensor(cand, device=prob0.device))
+        starts = np.concatenate([starts, cand[st.cpu().numpy() == 0]])
+    starts = starts[:B]
+    obs = prob0.forward(torch.tensor(starts[:1], device=prob0.device))[0][0].cpu().numpy() \
+        + 0.025 * rng.standard_normal(P)
+    prob = DeviceProblem(NL, 1.75, periods, obs, "normal", {"std": 0.025}, bounds)
+    return prob, starts
+
+
+def test_static_scratch_entry_point_matches_mhd_mh_steps():
+    import torch
+    from mcmc_amd.engine import DeviceChains
+    rng = np.random.default_rng(77)
+    # two calls in a row: 256 chains x 120 steps (a scheduled call of two launches), then 96
+    # chains x 100 steps on the same static scratch
+    for B, S in ((256, 120), (96, 100)):
+        prob, starts = _problem(rng, B)
+        dev, NP = prob.device, 2 * NL + 1
+        idx = torch.tensor(rng.integers(0, NP, (S, B)).astype(np.int32), device=dev)
+        cauchy = torch.tensor(np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5)), device=dev)
+        u_acc = torch.tensor(rng.uniform(size=(S, B)), device=dev)
+        res = []
+        for static in (False, True):
+            ch = DeviceChains(prob, starts, 0.05)
+            if static:
+                ch.sched = None           # the entry point must not need it
+            assert int((ch.init_likelihood() != 0).sum()) == 0
+            # two calls per case, so that the second finds the costs the first left
+            out1 = ch.steps(idx[:S // 2], cauchy[:S // 2], u_acc[:S // 2], hist_every=10,
+                            static_scratch=static)
+            out2 = ch.steps(idx[S // 2:], cauchy[S // 2:], u_acc[S // 2:], hist_every=10,
+                            static_scratch=static)
+            torch.cuda.synchronize()
+            res.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(),
+                        ch.params_prev.clone(),
+                        torch.cat([out1["accepted"], out2["accepted"]]),
+                        torch.cat([out1["status"], out2["status"]]),
+                        torch.cat([out1["hist_m"], out2["hist_m"]]),
+                        torch.cat([out1["hist_logL"], out2["hist_logL"]]),
+                        int(ch.n_evals[0])))
+        for x, y in zip(res[0][:-1], res[1][:-1]):
+            assert torch.equal(x, y)                      # integer and FP64 state: bit-exact
+        assert res[0][-1] == res[1][-1] > 0               # same sequential-algorithm evaluations
+        assert int(res[1][3][:, 0].sum()) > 0             # something was accepted
+
+
+def test_static_scratch_entry_point_refuses_what_it_cannot_hold():
+    import ctypes
+    import torch
+    from mcmc_amd import _lib as L
+    from mcmc_amd.engine import DeviceChains, _ptr, _stream
+    rng = np.random.default_rng(5)
+    prob, starts = _problem(rng, 8)
+    B = 4097
+    ch = DeviceChains(prob, np.tile(starts[:1], (B, 1)), 0.05)
+    z = torch.zeros((1, B), dtype=torch.float64, device=prob.device)
+    zi = torch.zeros((1, B), dtype=torch.int32, device=prob.device)
+    s = ch.struct()
+    rc = L.lib().mhd_mh_steps_static(prob.cref(), ctypes.byref(s), B, 1, _ptr(zi), _ptr(z), _ptr(z),
+                                     1.0, 0, 0, None, None, 0, None, None, None, None,
+                                     _stream(prob.device))
+    assert rc == -22 and b"4096" in L.lib().mhd_last_error()
