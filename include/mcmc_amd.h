@@ -237,6 +237,31 @@ int mhd_mh_steps_static(const mhd_problem_t *prob, const mhd_chains_t *chains, i
                         uint64_t *n_evals, void *stream);
 
 /*
+ * One parallel-tempering exchange sweep, Inversion.perform_tempering_swap
+ * (src/inversion/inversion.py:560-596), for n_ladders independent temperature
+ * ladders of n_temps rungs each.  logL and beta hold ALL replicas of the run
+ * (on several GPUs: logL after the all-gather of the ranks' blocks; every rank
+ * runs the same sweep on the same numbers and so keeps an identical copy of
+ * beta); replica (ladder l, rung t) is element l*ladder_stride + t*rung_stride.
+ * Within a ladder the adjacent pairs (t, t+1) are visited in order with the
+ * betas as the earlier pairs of this sweep left them; a pair with different
+ * betas is exchanged when
+ *     u[l, t] <= exp((beta2 - beta1) * (logL1 - logL2))
+ * (the reference's rule, :578-586).  An exchange swaps the two betas; chain
+ * states never move.  u is device [n_ladders, n_temps-1], host-supplied
+ * uniforms (the reference draws np.random.rand(1) per pair, :584).  counts, if
+ * not NULL, is device int64[2], incremented by {accepted, proposed} exchanges
+ * that involve a beta == 1 replica (swap_acc, swap_prop, :588-596).
+ * Deviations from the reference, both required for a working sampler: the
+ * reference decides an exchange and then changes nothing, and its flat loop
+ * knows one ladder only (here: n_ladders = 1, rung_stride = 1).
+ */
+int mhd_tempering_sweep(const double *logL /* device [R] */, double *beta /* device [R] */,
+                        const double *u /* device [n_ladders, n_temps-1] */, int32_t n_temps,
+                        int32_t n_ladders, int64_t rung_stride, int64_t ladder_stride,
+                        int64_t *counts, void *stream);
+
+/*
  * Model.update_covariance_matrix alone (src/inversion/model.py:263-282), used on
  * the steps where the reference refreshes the rotation matrix between the
  * covariance update and the proposal (model.py:183-193).

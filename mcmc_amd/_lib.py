@@ -32,6 +32,7 @@ EXPORTS = (
     "mhd_mh_steps",
     "mhd_mh_steps_static",
     "mhd_cov_accumulate",
+    "mhd_tempering_sweep",
 )
 
 
@@ -95,6 +96,8 @@ def lib():
                                c_void_p, c_void_p, c_void_p]
     L.mhd_mh_steps_static.argtypes = L.mhd_mh_steps.argtypes
     L.mhd_cov_accumulate.argtypes = [pp, cp, c_int32, c_void_p]
+    L.mhd_tempering_sweep.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                      ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)
     if L.mhd_abi_version() != ABI_VERSION:

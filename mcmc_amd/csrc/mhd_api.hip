@@ -414,6 +414,46 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     }
 }
 
+// ---- parallel tempering -------------------------------------------------------
+// One exchange sweep (src/inversion/inversion.py:560-596) for every temperature ladder: one lane
+// per ladder walks its adjacent pairs in order, rung t with rung t+1, with the betas as the
+// earlier pairs of the same sweep left them.  A pair with different betas is exchanged when
+// u <= exp((beta2 - beta1) * (logL1 - logL2)); the betas move, the states stay.  Replica (l, t)
+// sits at index l * ladder_stride + t * rung_stride of logL and beta.
+__global__ __launch_bounds__(64) void tempering_sweep_kernel(const double* logL, double* beta,
+                                                             const double* u, int n_temps,
+                                                             int n_ladders, long long rung_stride,
+                                                             long long ladder_stride,
+                                                             long long* counts)
+{
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= n_ladders) return;
+    long long acc = 0, prop = 0;
+    const long long base = (long long)l * ladder_stride;
+    double b1 = beta[base];
+    for (int t = 0; t + 1 < n_temps; ++t) {
+        const long long i1 = base + t * rung_stride, i2 = i1 + rung_stride;
+        const double b2 = beta[i2];
+        double keep = b2;  // what rung t+1 holds after this pair
+        if (b1 != b2) {
+            const double logratio = (b2 - b1) * (logL[i1] - logL[i2]);
+            const bool one = (b1 == 1.0) || (b2 == 1.0);
+            if (u[(long long)l * (n_temps - 1) + t] <= exp(logratio)) {
+                beta[i1] = b2;
+                beta[i2] = b1;
+                keep = b1;
+                acc += one;
+            }
+            prop += one;
+        }
+        b1 = keep;
+    }
+    if (counts) {
+        if (acc) atomicAdd((unsigned long long*)&counts[0], (unsigned long long)acc);
+        if (prop) atomicAdd((unsigned long long*)&counts[1], (unsigned long long)prop);
+    }
+}
+
 // ---- cost-aware launch schedule ---------------------------------------------
 // mhd_chains_t.sched, kept between calls: what a step of each chain cost last time (ticks of
 // the 100 MHz clock, scaled to one candidate in flight; 0 = not known yet), and what the next
@@ -1246,6 +1286,21 @@ int mhd_mh_steps_static(const mhd_problem_t* prob, const mhd_chains_t* chains, i
     return mh_steps_launch(prob, &ch, B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior,
                            accepted, status, hist_every, hist_m, hist_logL, hist_pred, n_evals,
                            (hipStream_t)stream, false);
+}
+
+int mhd_tempering_sweep(const double* logL, double* beta, const double* u, int32_t n_temps,
+                        int32_t n_ladders, int64_t rung_stride, int64_t ladder_stride,
+                        int64_t* counts, void* stream)
+{
+    if (n_temps < 1 || n_ladders < 0) return fail(MHD_EINVAL, "bad ladder shape");
+    if (rung_stride < 1 || ladder_stride < 1) return fail(MHD_EINVAL, "strides must be positive");
+    if (n_ladders == 0 || n_temps == 1) return MHD_OK;
+    if (!logL || !beta || !u) return fail(MHD_EINVAL, "NULL argument");
+    hipLaunchKernelGGL(tempering_sweep_kernel, dim3((n_ladders + 63) / 64), dim3(64), 0,
+                       (hipStream_t)stream, logL, beta, u, n_temps, n_ladders,
+                       (long long)rung_stride, (long long)ladder_stride, (long long*)counts);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_tempering_sweep launch");
 }
 
 int mhd_cov_accumulate(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,

@@ -256,6 +256,188 @@ __device__ MHD_NOINLINE SecVal eval_secular(int wave, double omega, double c)
     return v;
 }
 
+// Two abscissae in one lane: the same operations as secular_rayleigh for each, written side by
+// side so that the two dependency chains fill each other's FP64 latency (one wave issues a
+// dependent FP64 instruction every ~8 cycles, the pipe takes one every 4).  The branches on the
+// kind of wave (oscillating / evanescent) are taken for the pair: both sides alike -- the rule
+// when the two abscissae are neighbours of one search -- run interleaved, a mixed pair runs the
+// one-abscissa routine twice.
+__device__ __forceinline__ void osc_or_evan2(const double k[2], const double xk[2], double dpth,
+                                             double cs[2], double over_r[2], double times_r[2],
+                                             double em[2], double ex[2])
+{
+    const bool osc0 = k[0] < xk[0], osc1 = k[1] < xk[1];
+    const bool ev0 = k[0] > xk[0], ev1 = k[1] > xk[1];
+    if (osc0 && osc1) {
+        double s2[2], ir[2], r[2], arg[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            s2[u] = (k[u] + xk[u]) * fabs(k[u] - xk[u]);
+            ir[u] = rsqrt_pos(fmax(s2[u], 1.0e-300));
+            r[u] = s2[u] * ir[u];
+            arg[u] = r[u] * dpth;
+        }
+        if (arg[0] < 1.0e5 && arg[1] < 1.0e5) {
+            double sn[2], cn[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) sincos_pio2(arg[u], sn[u], cn[u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                cs[u] = cn[u];
+                over_r[u] = sn[u] * ir[u];
+                times_r[u] = -r[u] * sn[u];
+                em[u] = 1.0;
+                ex[u] = 0.0;
+            }
+            return;
+        }
+    } else if (ev0 && ev1) {
+        double s2[2], ir[2], r[2], arg[2], e1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            s2[u] = (k[u] + xk[u]) * fabs(k[u] - xk[u]);
+            ir[u] = rsqrt_pos(fmax(s2[u], 1.0e-300));
+            r[u] = s2[u] * ir[u];
+            arg[u] = r[u] * dpth;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) e1[u] = exp_neg(fmin(arg[u], 700.0));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            em[u] = e1[u];
+            const double fac = (arg[u] < 16.0) ? e1[u] * e1[u] : 0.0;
+            cs[u] = (1.0 + fac) * 0.5;
+            const double sh = (1.0 - fac) * 0.5;
+            over_r[u] = sh * ir[u];
+            times_r[u] = r[u] * sh;
+            ex[u] = arg[u];
+        }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        osc_or_evan(k[u], xk[u], dpth, cs[u], over_r[u], times_r[u], em[u], ex[u]);
+}
+
+__device__ __forceinline__ void secular_rayleigh2(const LayerTable& T, const double omega[2],
+                                                  const double c[2], double val[2], int sexp[2])
+{
+    const int L = T.L;
+    double k[2], k2[2], inv_om2[2], e0[2], e1[2], e2[2], e3[2], e4[2];
+    {
+        const int h = L - 1;
+        const double ia = T.inv_a[h], ib = T.inv_b[h], tb2 = T.twob2[h], rho1 = T.rho[h];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            inv_om2[u] = 1.0 / (omega[u] * omega[u]);
+            k[u] = omega[u] / c[u];
+            k2[u] = k[u] * k[u];
+            const double xka = omega[u] * ia, xkb = omega[u] * ib;
+            const double ra = sqrt((k[u] + xka) * fabs(k[u] - xka));
+            const double rb = sqrt((k[u] + xkb) * fabs(k[u] - xkb));
+            const double gammk = tb2 * inv_om2[u];
+            const double gam = gammk * k2[u];
+            const double gamm1 = gam - 1.0;
+            e0[u] = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
+            e1[u] = -rho1 * ra;
+            e2[u] = rho1 * (gamm1 - gammk * ra * rb);
+            e3[u] = rho1 * rb;
+            e4[u] = k2[u] - ra * rb;
+            sexp[u] = 0;
+        }
+    }
+#pragma nounroll
+    for (int m = L - 2; m >= 0; --m) {
+        const double ia = T.inv_a[m], ib = T.inv_b[m], tb2 = T.twob2[m];
+        const double dpth = T.d[m], rho1 = T.rho[m], irho = T.inv_rho[m];
+        double xka[2], xkb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            xka[u] = omega[u] * ia;
+            xkb[u] = omega[u] * ib;
+        }
+        double cosp[2], w[2], x[2], ep[2], pex[2], cosq[2], y[2], z[2], eq[2], sex[2];
+        osc_or_evan2(k, xka, dpth, cosp, w, x, ep, pex);
+        osc_or_evan2(k, xkb, dpth, cosq, y, z, eq, sex);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const double gammk = tb2 * inv_om2[u];
+            const double gam = gammk * k2[u];
+            const double a0 = (pex[u] + sex[u] < 60.0) ? ep[u] * eq[u] : 0.0;
+            const double cpcq = cosp[u] * cosq[u], cpy = cosp[u] * y[u], cpz = cosp[u] * z[u],
+                         cqw = cosq[u] * w[u], cqx = cosq[u] * x[u], xy = x[u] * y[u],
+                         xz = x[u] * z[u], wy = w[u] * y[u], wz = w[u] * z[u];
+            const double gamm1 = gam - 1.0;
+            const double twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1,
+                         gm1sq = gamm1 * gamm1, rho2 = rho1 * rho1, a0pq = a0 - cpcq,
+                         t = -2.0 * k2[u];
+            const double ca00 = cpcq - 2.0 * gmgm1 * a0pq - gmgmk * xz - k2[u] * gm1sq * wy;
+            const double ca01 = (k2[u] * cpy - cqx) * irho;
+            const double ca02 = -(twgm1 * a0pq + gammk * xz + k2[u] * gamm1 * wy) * irho;
+            const double ca03 = (cpz - k2[u] * cqw) * irho;
+            const double ca04 = -(2.0 * k2[u] * a0pq + xz + k2[u] * k2[u] * wy) * (irho * irho);
+            const double ca10 = (gmgmk * cpz - gm1sq * cqw) * rho1;
+            const double ca11 = cpcq;
+            const double ca12 = gammk * cpz - gamm1 * cqw;
+            const double ca13 = -wz;
+            const double ca30 = (gm1sq * cpy - gmgmk * cqx) * rho1;
+            const double ca31 = -xy;
+            const double ca32 = gamm1 * cpy - gammk * cqx;
+            const double ca40 =
+                -(2.0 * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * xz + gm1sq * gm1sq * wy) * rho2;
+            const double ca42 =
+                -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * xz + gamm1 * gm1sq * wy) *
+                rho1;
+            const double ca20 = t * ca42, ca21 = t * ca32, ca22 = a0 + 2.0 * (cpcq - ca00),
+                         ca23 = t * ca12, ca24 = t * ca02;
+            const double n0 = e0[u] * ca00 + e1[u] * ca10 + e2[u] * ca20 + e3[u] * ca30 + e4[u] * ca40;
+            const double n1 = e0[u] * ca01 + e1[u] * ca11 + e2[u] * ca21 + e3[u] * ca31 + e4[u] * ca30;
+            const double n2 = e0[u] * ca02 + e1[u] * ca12 + e2[u] * ca22 + e3[u] * ca32 + e4[u] * ca42;
+            const double n3 = e0[u] * ca03 + e1[u] * ca13 + e2[u] * ca23 + e3[u] * ca11 + e4[u] * ca10;
+            const double n4 = e0[u] * ca04 + e1[u] * ca03 + e2[u] * ca24 + e3[u] * ca01 + e4[u] * ca00;
+            const double t1 =
+                fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
+            const int ex = (t1 < 1.0e-40) ? 0 : __builtin_amdgcn_frexp_exp(t1);
+            sexp[u] += ex;
+            e0[u] = ldexp(n0, -ex);
+            e1[u] = ldexp(n1, -ex);
+            e2[u] = ldexp(n2, -ex);
+            e3[u] = ldexp(n3, -ex);
+            e4[u] = ldexp(n4, -ex);
+        }
+    }
+    val[0] = e0[0];
+    val[1] = e0[1];
+}
+
+struct SecVal2 {
+    double m0, m1;
+    int e0, e1;
+};
+
+// The out-of-line body for a pair of abscissae (Love waves: the one-abscissa routine twice, the
+// Love period equation is a tenth of the Rayleigh one).
+__device__ MHD_NOINLINE SecVal2 eval_secular2(int wave, double omega0, double c0, double omega1,
+                                              double c1)
+{
+    SecVal2 v;
+    const double om[2] = {fmax(omega0, 1.0e-4), fmax(omega1, 1.0e-4)};
+    const double cc[2] = {c0, c1};
+    if (wave == MHD_LOVE) {
+        v.m0 = secular_love(g_T, om[0], c0, &v.e0);
+        v.m1 = secular_love(g_T, om[1], c1, &v.e1);
+    } else {
+        double val[2];
+        int se[2];
+        secular_rayleigh2(g_T, om, cc, val, se);
+        v.m0 = val[0];
+        v.m1 = val[1];
+        v.e0 = se[0];
+        v.e1 = se[1];
+    }
+    return v;
+}
+
 __device__ __forceinline__ double secular(const LayerTable&, int wave, double omega, double c)
 {
     return eval_secular(wave, omega, c).m;

@@ -54,7 +54,6 @@ struct PredictScratch {
     int woff[9];      // ... and first lane
     // what the replay did for each period (see replay_period)
     double rstart[MAXP];
-    unsigned long long rbits[MAXP];
     int rmeta[MAXP];
     unsigned short roff[MAXP + 1];  // number of abscissae of the pass before the period's
     int trouble;  // repairs the last predicted curve needed (9: the predictor gave up)
@@ -800,178 +799,199 @@ __device__ __forceinline__ int predict_hint(int wave, const double* t, int P, do
 }
 
 // ---- stage 3 ----------------------------------------------------------------
-// getsol of period k with signs inferred from the bracket (same control flow and abscissa
-// arithmetic as solve_period_wave; every value is the same in all lanes).  Only the plain case:
-// a scan that meets neither the floor nor the ceiling, then halvings, no abscissa inside the
-// bracket.  What it did is kept as a summary -- start, direction, number of scan and halving
-// abscissae, the side taken at each halving -- from which replay_abscissa() regenerates any
-// abscissa it consumed.  Returns 1 (root found), 0 (the search ends above the ceiling) or
-// -1: not a plain case, nothing recorded.
-__device__ __forceinline__ int replay_period(int k, double& c1io, double clow, double dc,
-                                             double cm, double top, double betmx, bool ifirst,
-                                             int& s1st, int& count)
-{
-    PredictScratch& S = g_PS;
-    const double lo = uniform_value(S.lo[k]), hi = uniform_value(S.hi[k]);
-    const int slo = __builtin_amdgcn_readfirstlane((int)S.slo[k]);
-    const int shi = __builtin_amdgcn_readfirstlane((int)S.shi[k]);
-    if (slo == 0 || shi == 0 || slo == shi) {
-        CHAIN_EVENT(11)
-        return -1;
-    }
-    // slo != shi: the inferred sign of an abscissa is known by its side of the bracket alone
-    // (below: x <= lo).  The side is uniform; kept as a scalar, it costs no vector compare of
-    // signs, and the side of c1 cannot change during the halvings.
-    const double start = c1io;
-    double c1 = start, c2;
-    bool below1 = uni(c1 <= lo);
-    const int sfirst = below1 ? slo : shi;
-    const bool upward = ifirst || s1st * sfirst >= 0;
-    const double step = upward ? dc : -dc;
-    int ns = 1;
-    bool plain;
-    for (;;) {
-        c2 = c1 + step;
-        ++ns;
-        const bool below2 = uni(c2 <= lo);
-        plain = uni(c2 > clow) && (ns <= MAX_SCAN);
-        if (below1 != below2 || !plain || uni(c2 < cm || c2 >= top)) {
-            plain = plain && (below1 != below2);
-            break;
-        }
-        c1 = c2;
-    }
-    if (!plain) {
-        if (ns > MAX_SCAN) CHAIN_EVENT(12)
-        else if (!uni(c2 > clow)) CHAIN_EVENT(13)
-        else CHAIN_EVENT(14)
-        if (ifirst) CHAIN_EVENT(3)
-        return -1;
-    }
-    // The halvings.  (1) The stopping test |c1 - c2| <= 1e-6 c1 cannot succeed while the ends are
-    // more than 2^-19 of the larger one apart (2^-19 > 1e-6): for that many halvings, counted
-    // from the binary exponents, it is left out.  (2) Those halvings run in the scalar unit, on
-    // the bit patterns of the (positive, wave-uniform) doubles -- the vector unit is what limits
-    // the throughput of these kernels, and this loop is a fifth of a curve's vector instructions
-    // otherwise.  Within one binade the pattern of RN((c1 + c2) / 2) is the mean of the patterns,
-    // rounded half to even; positive doubles compare like their patterns (the borrow of a
-    // subtraction decides: the scalar unit has no ordered 64-bit compare).  The ends stay inside
-    // the binade they start in.  The verification pass checks every abscissa and every side
-    // taken here against the plain 0.5 * (c1 + c2) arithmetic of replay_abscissa.
-    unsigned long long bits = 0;
-    int nh = 0;
-    {
-        const int e_apart = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fabs(c1 - c2)));
-        const int e_ends = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fmax(c1, c2)));
-        // |c1 - c2| >= 2^(e_apart - 1), the ends stay below 2^e_ends: after n halvings the ends
-        // are at least 2^(e_apart - 1 - n - e_ends) of the larger one apart
-        int sure = e_apart - 1 - e_ends + 19;
-        sure = sure < 0 ? 0 : (sure > 38 ? 38 : sure);
-        unsigned b1l = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(c1));
-        unsigned b1h = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(c1));
-        unsigned b2l = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(c2));
-        unsigned b2h = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(c2));
-        const unsigned blol = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(lo));
-        const unsigned bloh = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(lo));
-        // (below1 as a 0/1 word in a scalar register: made from the vote itself, a select on the
-        // flag ends up in a vector register whatever the constraint says)
-        unsigned bel;
-        {
-            const unsigned long long vote = __ballot(start <= lo) | (unsigned long long)0;
-            asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(bel) : "s"(vote) : "scc");
-        }
-        if (((b1h ^ b2h) >> 20) != 0u) sure = 0;  // the ends are in two binades: all by the FP loop
-        unsigned long long sbits = 0;
-        for (int i = 0; i < sure; ++i) {
-            unsigned sl, sh, m3l, m3h, tt;
-            unsigned long long left64;
-            asm volatile(
-                "s_add_u32 %[sl], %[b1l], %[b2l]\n\t"
-                "s_addc_u32 %[sh], %[b1h], %[b2h]\n\t"
-                "s_lshr_b32 %[m3l], %[sl], 1\n\t"
-                "s_lshl_b32 %[tt], %[sh], 31\n\t"
-                "s_or_b32 %[m3l], %[m3l], %[tt]\n\t"
-                "s_lshr_b32 %[m3h], %[sh], 1\n\t"
-                "s_and_b32 %[tt], %[sl], %[m3l]\n\t"
-                "s_and_b32 %[tt], %[tt], 1\n\t"
-                "s_add_u32 %[m3l], %[m3l], %[tt]\n\t"
-                "s_addc_u32 %[m3h], %[m3h], 0\n\t"
-                "s_sub_u32 %[tt], %[blol], %[m3l]\n\t"
-                "s_subb_u32 %[tt], %[bloh], %[m3h]\n\t"
-                "s_cselect_b32 %[tt], 0, 1\n\t"
-                "s_xor_b32 %[tt], %[tt], %[bel]\n\t"
-                "s_cselect_b32 %[b2l], %[m3l], %[b2l]\n\t"
-                "s_cselect_b32 %[b2h], %[m3h], %[b2h]\n\t"
-                "s_cselect_b32 %[b1l], %[b1l], %[m3l]\n\t"
-                "s_cselect_b32 %[b1h], %[b1h], %[m3h]\n\t"
-                "s_cselect_b64 %[left64], 1, 0\n\t"
-                "s_lshl_b64 %[left64], %[left64], %[nh]\n\t"
-                "s_or_b64 %[sbits], %[sbits], %[left64]"
-                : [sl] "=&s"(sl), [sh] "=&s"(sh), [m3l] "=&s"(m3l), [m3h] "=&s"(m3h),
-                  [tt] "=&s"(tt), [left64] "=&s"(left64), [b1l] "+s"(b1l), [b1h] "+s"(b1h),
-                  [b2l] "+s"(b2l), [b2h] "+s"(b2h), [sbits] "+s"(sbits)
-                : [blol] "s"(blol), [bloh] "s"(bloh), [bel] "s"(bel), [nh] "s"(nh)
-                : "scc");
-            // (bit nh of sbits: the sign at the midpoint differs from the one at c1)
-            ++nh;
-        }
-        if (sure > 0) {
-            c1 = __hiloint2double((int)b1h, (int)b1l);
-            c2 = __hiloint2double((int)b2h, (int)b2l);
-            bits = sbits;
-        }
-    }
-    double c3 = 0.5 * (c1 + c2);
-    double last;
-    for (;;) {
-        const bool left = uni(c3 <= lo) != below1;
-        bits |= (unsigned long long)left << nh;
-        ++nh;
-        if (left) c2 = c3; else c1 = c3;
-        last = c3;
-        if (uni(fabs(c1 - c2) <= 1.0e-6 * c1)) break;
-        if (nh >= 40) return -1;
-        c3 = 0.5 * (c1 + c2);
-    }
-    c3 = last;
-    // an abscissa inside the bracket would have become an end of [c1, c2]
-    if (!uni(fmin(c1, c2) <= lo && fmax(c1, c2) >= hi)) {
-        CHAIN_EVENT(15)
-        return -1;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        S.rstart[k] = start;
-        S.rbits[k] = bits;
-        S.rmeta[k] = ns | (nh << 8) | ((int)upward << 16);
-    }
-    count = ns + nh;
-    if (ifirst) s1st = __builtin_amdgcn_readfirstlane(sfirst);
-    c1io = c3;
+// getsol of periods kstart..nP-1, one after the other, with signs inferred from the roots (same
+// control flow and abscissa arithmetic as solve_period_wave; every value is the same in all
+// lanes).  Only the plain case: a scan that meets neither the floor nor the ceiling, then
+// halvings, no abscissa inside the root's bracket.  What it did for a period is kept as a
+// summary -- start, direction, number of scan and halving abscissae -- from which
+// replay_abscissae() regenerates any abscissa it consumed.
+//
+// This is one chain of dependent operations through all periods (a period starts 1.5 dc below
+// the answer of the one before), so it is written for latency: the brackets are loaded once,
+// lane j holding period kb + j, and reach the chain through v_readlane; the summaries are
+// gathered in the lanes' registers and stored after the chain; the chain itself touches no LDS.
+// A halving is an add, a multiply, a compare and two selects.  The stopping test
+// |c1 - c2| <= 1e-6 c1 cannot succeed while the ends are more than 2^-19 of the larger one
+// apart (2^-19 > 1e-6): for that many halvings, counted from the binary exponents, it is left
+// out.  The verification regenerates every abscissa with the plain arithmetic of
+// replay_abscissae and checks the answer of every period against it.
+struct ReplayPass {
+    int kend;    // periods kstart..kend-1 were replayed (summaries and roff[] are valid)
+    int kfail;   // >= 0: the search of this period (= kend-1) ends above the ceiling
+    int kplain;  // >= 0: this period (= kend) is not a plain case; nothing recorded for it
+    int npts;    // abscissae consumed by the periods replayed
+};
 
-    return uni(c3 <= betmx) ? 1 : 0;
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
 
-// The q-th abscissa replay_period consumed for period k (any lane, any k and q).
-__device__ __forceinline__ double replay_abscissa(int k, int q, double dc)
+__device__ __forceinline__ ReplayPass replay_pass(int kstart, int nP, double* c, double cc,
+                                                  double dc, double top, double betmx, int& s1st)
+{
+    PredictScratch& S = g_PS;
+    const int lane = threadIdx.x & 63;
+    kstart = __builtin_amdgcn_readfirstlane(kstart);
+    nP = __builtin_amdgcn_readfirstlane(nP);
+    ReplayPass o = {kstart, -1, -1, 0};
+    double cprev = kstart > 0 ? uniform_value(c[kstart - 1]) : 0.0;
+    int s1 = s1st;
+    for (int kb = kstart; kb < nP; kb += 64) {
+        const int kmine = kb + lane;
+        const bool mine = kmine < nP;
+        const double lo_v = mine ? S.lo[kmine] : 0.0, hi_v = mine ? S.hi[kmine] : 0.0;
+        const int sg_v = mine ? (((int)S.slo[kmine] & 0xff) | (((int)S.shi[kmine] & 0xff) << 8)) : 0;
+        double r_start = 0.0, r_c = 0.0;
+        int r_meta = 0, r_off = 0;
+        const int kchunk = (nP - kb < 64) ? nP - kb : 64;
+        bool stop = false;
+        for (int kk = 0; kk < kchunk; ++kk) {
+            const int k = kb + kk;
+            const double lo = readlane_f64(lo_v, kk), hi = readlane_f64(hi_v, kk);
+            const int sg = __builtin_amdgcn_readlane(sg_v, kk);
+            const int slo = (int)(signed char)(sg & 0xff), shi = (int)(signed char)((sg >> 8) & 0xff);
+            const bool ifirst = (k == 0);
+            const double start = ifirst ? cc : cprev - 1.5 * dc;
+            double c1 = start, c2 = start;
+            const bool below1 = uni(c1 <= lo);
+            const int sfirst = below1 ? slo : shi;
+            const bool upward = ifirst || s1 * sfirst >= 0;
+            // the scan arrives at the root only when it moves towards it
+            bool plain = slo != 0 && shi != 0 && slo != shi && (upward == below1);
+            const double step = upward ? dc : -dc;
+            int ns = 1;
+            if (plain) {
+                for (;;) {
+                    c2 = c1 + step;
+                    ++ns;
+                    // (the floor is both clow and cm in the fundamental mode)
+                    if (uni((c2 <= lo) != below1)) {
+                        plain = uni(c2 > cc) && ns <= MAX_SCAN;
+                        break;
+                    }
+                    if (uni(!(c2 > cc) || c2 >= top) || ns >= MAX_SCAN) {
+                        plain = false;
+                        break;
+                    }
+                    c1 = c2;
+                }
+            }
+            int nh = 0;
+            double c3 = 0.0;
+            if (plain) {
+                const int e_apart =
+                    __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fabs(c1 - c2)));
+                const int e_ends =
+                    __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fmax(c1, c2)));
+                // |c1 - c2| >= 2^(e_apart - 1), the ends stay below 2^e_ends: after n halvings
+                // the ends are at least 2^(e_apart - 1 - n - e_ends) of the larger one apart
+                int sure = e_apart - 1 - e_ends + 19;
+                sure = sure < 0 ? 0 : (sure > 38 ? 38 : sure);
+                // (below1 fixes which end a midpoint on the root's lower side replaces: two copies
+                // of the loop, no flag to combine with the compare)
+                if (below1) {
+#pragma unroll 4
+                    for (; nh < sure; ++nh) {
+                        c3 = 0.5 * (c1 + c2);
+                        const bool low = c3 <= lo;
+                        c1 = low ? c3 : c1;
+                        c2 = low ? c2 : c3;
+                    }
+                } else {
+#pragma unroll 4
+                    for (; nh < sure; ++nh) {
+                        c3 = 0.5 * (c1 + c2);
+                        const bool low = c3 <= lo;
+                        c2 = low ? c3 : c2;
+                        c1 = low ? c1 : c3;
+                    }
+                }
+                bool converged = false;
+                while (nh < 40) {
+                    c3 = 0.5 * (c1 + c2);
+                    const bool left = (c3 <= lo) != below1;
+                    ++nh;
+                    c2 = left ? c3 : c2;
+                    c1 = left ? c1 : c3;
+                    if (__ballot(fabs(c1 - c2) <= 1.0e-6 * c1) != 0ull) {
+                        converged = true;
+                        break;
+                    }
+                }
+                plain = converged;
+                // an abscissa inside the bracket would have become an end of [c1, c2]
+                plain = plain && uni(fmin(c1, c2) <= lo && fmax(c1, c2) >= hi);
+            }
+            if (!plain) {
+                o.kplain = k;
+                stop = true;
+                break;
+            }
+            if (lane == kk) {
+                r_start = start;
+                r_meta = ns | (nh << 8) | ((int)upward << 16);
+                r_off = o.npts;
+                r_c = c3;
+            }
+            o.npts += ns + nh;
+            o.kend = k + 1;
+            if (ifirst) s1 = __builtin_amdgcn_readfirstlane(sfirst);
+            cprev = c3;
+            if (!uni(c3 <= betmx)) {
+                o.kfail = k;
+                stop = true;
+                break;
+            }
+        }
+        if (mine && kmine < o.kend) {
+            S.rstart[kmine] = r_start;
+            S.rmeta[kmine] = r_meta;
+            S.roff[kmine] = (unsigned short)r_off;
+            if (kmine != o.kfail) c[kmine] = r_c;
+        }
+        if (stop) break;
+    }
+    if (lane == 0) S.roff[o.kend] = (unsigned short)o.npts;
+    s1st = s1;
+    wave_sync();
+    return o;
+}
+
+// Abscissae q and q + 1 that replay_pass consumed for period k (any lane, any k and q), by the
+// arithmetic of the sequential search: the scan adds the step, a halving takes the midpoint and
+// moves the end that lies on the midpoint's side of the root.  xb is meaningless when q is the
+// period's last abscissa.
+__device__ __forceinline__ void replay_abscissae(int k, int q, double dc, double& xa, double& xb)
 {
     const PredictScratch& S = g_PS;
     const int meta = S.rmeta[k];
     const int ns = meta & 255;
     const double step = (meta >> 16) ? dc : -dc;
-    const unsigned long long bits = S.rbits[k];
-    double c1 = S.rstart[k], c2 = c1;
-    const int nscan = q < ns - 1 ? q : ns - 1;
-    for (int j = 0; j < nscan; ++j) {
-        c1 = c2;
-        c2 = c2 + step;
+    const double lo = S.lo[k];
+    const double start = S.rstart[k];
+    const bool below1 = start <= lo;
+    double c1 = start, c2 = start, c3 = start, x = start;
+    xa = start;
+    for (int j = 1; j <= q + 1; ++j) {
+        if (j < ns) {
+            c1 = c2;
+            c2 = c2 + step;
+            x = c2;
+        } else {
+            if (j > ns) {
+                const bool left = (c3 <= lo) != below1;
+                c2 = left ? c3 : c2;
+                c1 = left ? c1 : c3;
+            }
+            c3 = 0.5 * (c1 + c2);
+            x = c3;
+        }
+        if (j == q) xa = x;
     }
-    if (q < ns) return c2;
-    double c3 = 0.0;
-    for (int i = 0; i <= q - ns; ++i) {
-        c3 = 0.5 * (c1 + c2);
-        if ((bits >> i) & 1ull) c2 = c3; else c1 = c3;
-    }
-    return c3;
+    xb = x;
 }
 
 // ---- the curve ---------------------------------------------------------------
@@ -1024,36 +1044,11 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
     for (;;) {
         // replay periods kstart..kend-1 (c[kstart-1] and s1st are exact); period kplain, if
         // any, is not a plain case and ends the pass
-        int npts = 0, kfail = -1, kplain = -1, kend = kstart;
-        double c1 = cc;
-        for (int k = kstart; k < nP; ++k) {
-            const bool ifirst = (k == 0);
-            double clow;
-            if (ifirst) {
-                clow = cc;
-                c1 = cc;
-            } else {
-                clow = cm;
-                c1 = uniform_value(c[k - 1]) - 1.5 * dc;
-            }
-            int count = 0;
-            const int r = replay_period(k, c1, clow, dc, cm, betmx + dc, betmx, ifirst, s1st, count);
-            if (r < 0) {
-                kplain = k;
-                CHAIN_EVENT(7)
-                break;
-            }
-            if (lane == 0) S.roff[k] = (unsigned short)npts;
-            npts += count;
-            kend = k + 1;
-            if (r == 0) {
-                kfail = k;
-                break;
-            }
-            c[k] = c1;
-        }
-        if (lane == 0) S.roff[kend] = (unsigned short)npts;
-        wave_sync();
+        const ReplayPass rp = replay_pass(kstart, nP, c, cc, dc, betmx + dc, betmx, s1st);
+        const int npts = rp.npts, kfail = rp.kfail, kplain = rp.kplain, kend = rp.kend;
+#ifdef MHD_PROFILE
+        if (kplain >= 0) CHAIN_EVENT(7)
+#endif
         PROF_ADD(2)
         // the period abscissa i of this pass belongs to
         auto period_of = [&](int i) -> int {
@@ -1069,31 +1064,38 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
         bool again = false;           // replay again from kstart
         for (;;) {
             int first_bad = npts;
-            for (int base = vbeg; base < npts; base += 64) {
-                const int i = base + lane;
-                const bool act = i < npts;
-                bool bad = false;
-                if (act) {
-                    const int k = period_of(i);
-                    const int q = i - (int)S.roff[k];
-                    const double x = replay_abscissa(k, q, dc);
-                    const bool below = x <= S.lo[k];
-                    const int want = below ? (int)S.slo[k] : (int)S.shi[k];
-                    const double omega = TWOPI / (t[k] / tscale);
-                    bad = sgni(eval_secular(wave, omega, x).m) != want;
-                    // the replay's own arithmetic: the side it took at this halving, and the
-                    // answer it gave for the period
-                    const int meta = S.rmeta[k], ns = meta & 255, nh = (meta >> 8) & 255;
-                    if (q >= ns) {
-                        const bool took_left = (S.rbits[k] >> (q - ns)) & 1ull;
-                        bad = bad || took_left != (below != (S.rstart[k] <= S.lo[k]));
-                        if (q == ns + nh - 1 && k != kfail) bad = bad || x != c[k];
-                    }
+            // two abscissae per lane, neighbours of one period's search as a rule
+            for (int base = vbeg; base < npts; base += 128) {
+                const int i0 = base + 2 * lane, i1 = i0 + 1;
+                const bool act0 = i0 < npts, act1 = i1 < npts;
+                bool bad0 = false, bad1 = false;
+                if (act0) {
+                    const int k0 = period_of(i0);
+                    const int q0 = i0 - (int)S.roff[k0];
+                    const bool same = !act1 || i1 < (int)S.roff[k0 + 1];
+                    const int k1 = same ? k0 : k0 + 1;
+                    double x0, x1;
+                    replay_abscissae(k0, q0, dc, x0, x1);
+                    if (!same) x1 = S.rstart[k1];
+                    if (!act1) x1 = x0;
+                    const double omega0 = TWOPI / (t[k0] / tscale);
+                    const double omega1 = same ? omega0 : TWOPI / (t[k1] / tscale);
+                    const SecVal2 v = eval_secular2(wave, omega0, x0, omega1, x1);
+                    const int want0 = (x0 <= S.lo[k0]) ? (int)S.slo[k0] : (int)S.shi[k0];
+                    const int want1 = (x1 <= S.lo[k1]) ? (int)S.slo[k1] : (int)S.shi[k1];
+                    bad0 = sgni(v.m0) != want0;
+                    bad1 = act1 && sgni(v.m1) != want1;
+                    // the answer the replay gave for the period: its last abscissa
+                    const int last0 = (int)S.roff[k0 + 1] - 1, last1 = (int)S.roff[k1 + 1] - 1;
+                    if (i0 == last0 && k0 != kfail) bad0 = bad0 || x0 != c[k0];
+                    if (act1 && i1 == last1 && k1 != kfail) bad1 = bad1 || x1 != c[k1];
                 }
-                const unsigned long long mask = __ballot(bad);
-                cnt.exec += (unsigned long long)__popcll(__ballot(act));
-                if (mask) {
-                    first_bad = base + (int)__ffsll((long long)mask) - 1;
+                const unsigned long long m0 = __ballot(bad0), m1 = __ballot(bad1);
+                cnt.exec += (unsigned long long)(__popcll(__ballot(act0)) + __popcll(__ballot(act1)));
+                if (m0 | m1) {
+                    const int f0 = m0 ? base + 2 * ((int)__ffsll((long long)m0) - 1) : npts;
+                    const int f1 = m1 ? base + 2 * ((int)__ffsll((long long)m1) - 1) + 1 : npts;
+                    first_bad = f0 < f1 ? f0 : f1;
                     break;
                 }
             }
@@ -1141,15 +1143,6 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
                 else if (kbad >= 20) CHAIN_EVENT(23)
                 else if (kbad >= 10) CHAIN_EVENT(24)
                 else CHAIN_EVENT(25)
-            }
-#endif
-#ifdef MHD_DEBUG_REPAIR
-            if (lane == 0) {
-                const int qb = first_bad - (int)S.roff[kbad];
-                printf("repair k %d hinted %d | scan start %.6f predicted root %.6f (slo %d) found %.6f | prev c %.6f | hint k-1 %.6f k %.6f | wrong sign at abscissa %d of %d scan + %d halvings, x %.6f | roots k-2..k+2: %.5f %.5f %.5f %.5f %.5f\n",
-                       kbad, S.hinted, (kbad ? c[kbad - 1] - 1.5 * dc : cc), S.lo[kbad], (int)S.slo[kbad], cr, kbad ? c[kbad - 1] : 0.0,
-                       use_hint && kbad ? hint[kbad - 1] : 0.0, use_hint ? hint[kbad] : 0.0, qb, S.rmeta[kbad] & 255, (S.rmeta[kbad] >> 8) & 255,
-                       replay_abscissa(kbad, qb, dc), kbad > 1 ? S.lo[kbad - 2] : 0.0, kbad ? S.lo[kbad - 1] : 0.0, S.lo[kbad], kbad + 1 < nP ? S.lo[kbad + 1] : 0.0, kbad + 2 < nP ? S.lo[kbad + 2] : 0.0);
             }
 #endif
             c[kbad] = cr;
