@@ -123,9 +123,19 @@ def main():
     ap.add_argument("--wave", choices=["rayleigh", "love"], default="rayleigh")
     ap.add_argument("--rotation", choices=["off", "on"], default="off",
                     help="on: rotated-frame proposals and covariance accumulation every step")
+    ap.add_argument("--tempering", action="store_true",
+                    help="parallel tempering: the chains of every GPU are ladders of --temps "
+                         "temperatures; after every --thin steps the ranks all-gather logL "
+                         "(RCCL) and run the exchange sweep, inside the timed region")
+    ap.add_argument("--temps", type=int, default=64)
+    ap.add_argument("--thin", type=int, default=10, help="MH steps between two exchange sweeps")
     args = ap.parse_args()
-    headline = (args.layers, args.itype, args.wave, args.rotation, args.chains) == \
-        (N_LAYERS, "phase", "rayleigh", "off", CHAINS_PER_GPU)
+    headline = (args.layers, args.itype, args.wave, args.rotation, args.chains, args.tempering) == \
+        (N_LAYERS, "phase", "rayleigh", "off", CHAINS_PER_GPU, False)
+    if args.tempering:
+        args.chunk = args.thin
+        if args.chains % args.temps:
+            raise SystemExit("--chains must be a multiple of --temps")
 
     import torch
     import torch.distributed as dist
@@ -156,7 +166,20 @@ def main():
     prob = DeviceProblem(nl, VPVS, periods, obs, "normal", {"std": STD}, bounds, **kind)
     rng = np.random.default_rng(1000 + rank)
     starts = prior_starts(prob, bounds, B, rng)
-    chains = DeviceChains(prob, starts, 0.05)
+    beta_all = logL_all = swap_counts = None
+    if args.tempering:
+        # ladders of --temps rungs, rungs of a ladder neighbours: every rank owns whole ladders
+        # but gathers logL and sweeps all of them, as a run with any other layout must
+        from mcmc_amd.engine import tempering_sweep
+        n_ladders = world * B // args.temps
+        nf = int(np.ceil(args.temps / 4))
+        ladder = np.ones(args.temps)
+        ladder[nf:] = 1.0 / 1.15 ** np.arange(nf, args.temps)
+        beta_all = torch.tensor(np.tile(ladder, n_ladders), device=prob.device)
+        logL_all = torch.zeros(world * B, dtype=torch.float64, device=prob.device)
+        swap_counts = torch.zeros(2, dtype=torch.int64, device=prob.device)
+    chains = DeviceChains(prob, starts, 0.05,
+                          beta=None if beta_all is None else beta_all[rank * B:(rank + 1) * B])
     assert int((chains.init_likelihood() != 0).sum()) == 0
     rotate = 3 if args.rotation == "on" else 0  # identity rotation matrices: same proposals
 
@@ -167,12 +190,25 @@ def main():
     cauchy = torch.tensor(np.tan(np.pi * (drng.uniform(size=(total, B)) - 0.5)), device=dev)
     u_acc = torch.tensor(drng.uniform(size=(total, B)), device=dev)
 
+    u_swap = None
+    if args.tempering:
+        n_sweeps = (total + args.thin - 1) // args.thin
+        u_swap = torch.tensor(np.random.default_rng(99).uniform(
+            size=(n_sweeps, world * B // args.temps, args.temps - 1)), device=dev)
+
     def run(lo, hi):
         n_launch = 0
         for a in range(lo, hi, args.chunk):
             b = min(hi, a + args.chunk)
             chains.steps(idx[a:b], cauchy[a:b], u_acc[a:b], rotate=rotate, want_flags=False)
             n_launch += 1
+            if args.tempering:
+                full = chains.logL
+                if world > 1:
+                    dist.all_gather_into_tensor(logL_all, chains.logL)
+                    full = logL_all
+                tempering_sweep(full, beta_all, u_swap[a // args.thin], args.temps,
+                                world * B // args.temps, 1, args.temps, swap_counts)
         return n_launch
 
     run(0, W)
@@ -207,6 +243,10 @@ def main():
         line = {
             "metric": "MH steps/sec (whole node), 6-layer Rayleigh, 1024 chains x 40 periods"
                       if headline else
+                      f"MH steps/sec (whole node), parallel tempering: {args.temps} temperatures x "
+                      f"{world * B // args.temps} ladders, {B} replicas per GPU, exchange sweep "
+                      f"(all-gather of logL + device sweep) every {args.thin} steps"
+                      if args.tempering else
                       f"MH steps/sec (whole node), {nl}-layer {args.wave} {args.itype} velocity, "
                       f"{B} chains x 40 periods, rotation {args.rotation}",
             "value": world * B * K / elapsed,
@@ -223,13 +263,19 @@ def main():
             "config": {
                 "workload": "configs[1]: 6-layer Rayleigh fundamental-mode phase-velocity "
                             "inversion, 1024 independent chains x 40 periods per GPU"
-                            if headline else "variant of configs[1] (see metric)",
+                            if headline else
+                            "configs[2]: parallel tempering, replicas sharded over the GPUs, "
+                            "all-gather of logL per sweep" if args.tempering else
+                            "variant of configs[1] (see metric)",
                 "chains_per_gpu": B, "n_periods": N_PERIODS, "n_layers": nl,
                 "wave": args.wave, "itype": args.itype,
                 "proposal": "cauchy", "likelihood": "normal", "rotation": args.rotation,
                 "steps_per_call": min(args.chunk, K), "calls_timed": n_launch,
                 "search": args.search,
                 "candidates_in_flight": args.candidates, "acceptance_rate": round(acc_rate, 4),
+                **({"temperatures": args.temps, "steps_between_sweeps": args.thin,
+                    "exchanges_accepted_proposed": swap_counts.tolist()}
+                   if args.tempering else {}),
             },
             "roofline": {
                 "bound": "valu_fp64",

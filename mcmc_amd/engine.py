@@ -162,8 +162,15 @@ class DeviceChains:
         self.counters = torch.zeros((B, 5), dtype=torch.int64, device=dev)
         self.counters_ind = torch.zeros((B, NP, 5), dtype=torch.int64, device=dev) \
             if individual_acceptance else None
-        self.beta = None if beta is None else torch.tensor(
-            np.asarray(beta, dtype=np.float64), **f64)
+        # (a tensor is used as it is: a view into the vector of all replicas' betas that the
+        # tempering sweep updates in place)
+        if beta is None or torch.is_tensor(beta):
+            self.beta = beta
+        else:
+            self.beta = torch.tensor(np.asarray(beta, dtype=np.float64), **f64)
+        if self.beta is not None:
+            assert self.beta.shape == (B,) and self.beta.dtype == torch.float64 \
+                and self.beta.is_contiguous() and self.beta.device == self.m.device
         self.n_evals = torch.zeros(2, dtype=torch.int64, device=dev)
         self.sched = torch.zeros(int(L.lib().mhd_sched_bytes(B)), dtype=torch.uint8, device=dev)
 
@@ -230,3 +237,21 @@ class DeviceChains:
         with torch.cuda.device(self.prob.device):
             L.check(L.lib().mhd_cov_accumulate(self.prob.cref(), ctypes.byref(ch), self.B,
                                                _stream(self.prob.device)))
+
+
+def tempering_sweep(logL_all, beta_all, u, n_temps, n_ladders, rung_stride, ladder_stride,
+                    counts=None):
+    """mhd_tempering_sweep on device tensors: logL_all, beta_all [R] (beta_all is updated in
+    place), u [n_ladders, n_temps-1], counts int64[2] or None."""
+    dev = beta_all.device
+    assert logL_all.dtype == beta_all.dtype == u.dtype == torch.float64
+    assert logL_all.is_contiguous() and beta_all.is_contiguous() and u.is_contiguous()
+    assert u.numel() == n_ladders * max(n_temps - 1, 0)
+    R = beta_all.numel()
+    assert logL_all.numel() == R
+    last = (n_ladders - 1) * ladder_stride + (n_temps - 1) * rung_stride
+    assert 0 <= last < R, "ladder layout reaches beyond the replicas"
+    with torch.cuda.device(dev):
+        L.check(L.lib().mhd_tempering_sweep(_ptr(logL_all), _ptr(beta_all), _ptr(u), int(n_temps),
+                                            int(n_ladders), int(rung_stride), int(ladder_stride),
+                                            _ptr(counts), _stream(dev)))

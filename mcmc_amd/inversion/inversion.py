@@ -1,16 +1,17 @@
 """Sampler loop -- mirror of src/inversion/inversion.py for the hot path.
 
 `Inversion` keeps the reference's constructor and `random_walk` signature.  All
-chains of this process are stepped by one `mhd_mh_steps` launch per segment
-(the step x chain x thin nest of src/inversion/inversion.py:388-414); the
-parallel-tempering exchange (:560-596) and the rotation refresh (SVD,
-src/inversion/model.py:284-293) stay on the host, as they do in the reference.
+chains of this process are stepped by `mhd_mh_steps` launches (the step x chain
+x thin nest of src/inversion/inversion.py:388-414).  The parallel-tempering
+exchange (:560-596) runs on the device (`mhd_tempering_sweep`) between two
+launches, without a host synchronisation; the rotation refresh (SVD,
+src/inversion/model.py:284-293) stays on the host, as in the reference.
 
 Differences from the reference, all deliberate:
-  * Draws are generated per segment as arrays [steps, chains] from np.random
-    (randint, uniform, uniform): the reference interleaves them per chain and
-    skips the accept uniform for invalid proposals, so a run with the same seed
-    visits different states; parity is defined on supplied draws
+  * Draws are generated as arrays [steps, chains] from np.random (randint,
+    uniform, uniform): the reference interleaves them per chain and skips the
+    accept uniform for invalid proposals, so a run with the same seed visits
+    different states; parity is defined on supplied draws
     (`Inversion.step_segment`).
   * get_betas: the reference leaves the first ceil(n/4) betas at 0 although its
     comment says they should be 1 (src/inversion/inversion.py:293-300); they are
@@ -19,14 +20,20 @@ Differences from the reference, all deliberate:
     changes nothing (and raises AttributeError on its uninitialised counters,
     src/inversion/inversion.py:586-596).  Here an accepted exchange swaps the
     two betas, and a chain's accept test uses exp(beta*dlogL/T).
+  * n_temps (not in the reference): n_chains independent temperature ladders of
+    n_temps rungs each, n_temps * n_chains replicas in all, exchanges inside each
+    ladder.  Without it the reference's meaning holds: n_chains > 1 is ONE ladder
+    with n_chains rungs.
   * Results go to chunked .npz files (input-<name>.npz once, results-<name>-
     <chunk>.npz every n_chunk steps) with the reference's variable names
     (src/inversion/inversion.py:150-231) instead of a netCDF file that is re-read
-    and rewritten every chunk.
+    and rewritten every chunk.  A tempered run records every replica of the
+    process together with its beta at each step (the reference keeps the
+    beta == 1 chains, :442); select with `beta == 1`.
 Multi-GPU: when torch.distributed is initialised, every rank owns a contiguous
-block of n_chains / world_size chains; the only exchange is one all-gather of
-the per-chain logL per tempering sweep, after which every rank takes the same
-swap decisions from the same uniforms and updates the betas it owns.
+block of the replicas; the only exchange is one all-gather of the per-replica
+logL per tempering sweep, after which every rank runs the same sweep on the
+same numbers and so holds the same betas.
 """
 import os
 
@@ -42,20 +49,32 @@ class _ChainView:
     class _MP:
         pass
 
-    def __init__(self, inv, i):
-        self.beta = float(inv.betas[inv._lo + i])
+    def __init__(self, inv, i, betas):
+        self.beta = float(betas[inv._lo + i])
         self.logL = float(inv._logL_host[i])
         self.model_params = _ChainView._MP()
         self.model_params.model_params = inv._m_host[i].copy()
         self.data_pred = inv._pred_host[i].copy()
 
 
+def ladder_layout(n_temps, n_ladders, layout):
+    """(rung_stride, ladder_stride) of replica (ladder l, rung t) = l*ladder_stride + t*rung_stride.
+    "ladder": the rungs of a ladder are neighbours (a rank's block holds whole ladders when its
+    size is a multiple of n_temps); "rung": the replicas of one temperature are neighbours
+    (adjacent rungs of a ladder may sit on different ranks)."""
+    if layout == "ladder":
+        return 1, n_temps
+    if layout == "rung":
+        return n_ladders, 1
+    raise ValueError("layout must be 'ladder' or 'rung'")
+
+
 class Inversion:
     def __init__(self, data, model_params, noise_dist, noise_params, n_burn, n_chunk, n_mcmc,
                  n_cov_chunk=200, n_thin=1, n_chains=1, individual_acceptance=False,
                  beta_spacing_factor=None, out_filename=None, set_starting_model=False,
-                 out_dir="./results/inversion/", reference_betas=False, swap_seed=0):
-        import torch
+                 out_dir="./results/inversion/", reference_betas=False, swap_seed=0,
+                 n_temps=None, layout="ladder"):
         import torch.distributed as dist
         self.data = data
         self.n_burn, self.n_chunk, self.n_mcmc, self.n_thin = n_burn, n_chunk, n_mcmc, n_thin
@@ -65,15 +84,21 @@ class Inversion:
         self.noise_dist, self.noise_params = noise_dist, noise_params
         self.n_chains = n_chains
         self.reference_betas = reference_betas
+        # temperature ladders: the reference's flat ladder over all chains, or n_chains ladders
+        if n_temps is None:
+            self.n_temps, self.n_ladders = n_chains, 1
+        else:
+            self.n_temps, self.n_ladders = int(n_temps), n_chains
+        self.n_replicas = self.n_temps * self.n_ladders
+        self.tempering = self.n_temps > 1
+        self.rung_stride, self.ladder_stride = ladder_layout(self.n_temps, self.n_ladders, layout)
         self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if n_chains % self.world:
-            raise ValueError("n_chains must be a multiple of the number of ranks")
-        self.n_local = n_chains // self.world
+        if self.n_replicas % self.world:
+            raise ValueError("the number of replicas must be a multiple of the number of ranks")
+        self.n_local = self.n_replicas // self.world
         self._lo = self.rank * self.n_local
         self.swap_rng = np.random.RandomState(swap_seed)  # identical on every rank
-        self.swap_acc = 0
-        self.swap_prop = 0
         self.out_dir = out_dir
         # results are written only when the caller names a file (the reference makes up a name
         # from the clock, src/inversion/inversion.py:62-66; with several ranks those would differ)
@@ -84,16 +109,25 @@ class Inversion:
             self.define_input_dataset(data, model_params, noise_dist, noise_params)
 
     # ------------------------------------------------------------------ set-up
-    def get_betas(self, beta_spacing_factor):
-        """Tempering ladder (src/inversion/inversion.py:274-300)."""
-        if self.n_chains == 1:
+    def get_betas(self, beta_spacing_factor, n_temps=None):
+        """Tempering ladder of n_temps rungs (src/inversion/inversion.py:274-300; there
+        n_temps = n_chains)."""
+        n_temps = self.n_chains if n_temps is None else n_temps
+        if n_temps == 1:
             return np.array([1.0])
-        n_temps = self.n_chains
         n_frac = int(np.ceil(n_temps / 4))
         betas = np.zeros(n_temps, dtype=float) if self.reference_betas else np.ones(n_temps)
         inds = np.arange(n_frac, n_temps)
         betas[inds] = 1.0 / beta_spacing_factor ** inds
         return betas
+
+    def replica_betas(self, beta_spacing_factor):
+        """Starting beta of every replica: each ladder holds get_betas(n_temps) on its rungs."""
+        ladder = self.get_betas(beta_spacing_factor, self.n_temps)
+        out = np.empty(self.n_replicas)
+        for l in range(self.n_ladders):
+            out[l * self.ladder_stride + np.arange(self.n_temps) * self.rung_stride] = ladder
+        return out
 
     def initialize_chains(self, model_params, noise_dist, noise_params, n_cov_chunk,
                           individual_acceptance, beta_spacing_factor, set_starting_model=False):
@@ -102,7 +136,6 @@ class Inversion:
         until the forward model succeeds."""
         import torch
         from ..engine import DeviceChains
-        self.betas = np.asarray(self.get_betas(beta_spacing_factor), dtype=float)
         pb = model_params.assemble_param_bounds()
         NP = model_params.n_model_params
         n = self.n_local
@@ -119,14 +152,34 @@ class Inversion:
                 todo = todo[~ok]
         self.prob = model_params.device_problem(self.data.periods, self.data.data_obs, noise_dist,
                                                 noise_params, with_bounds=True)
+        dev = self.prob.device
+        # every rank holds the betas of ALL replicas (the sweep updates them identically
+        # everywhere); the chains of this rank read their block of it
+        self.beta_all = torch.tensor(self.replica_betas(beta_spacing_factor), dtype=torch.float64,
+                                     device=dev)
+        self.logL_all = torch.zeros(self.n_replicas, dtype=torch.float64, device=dev)
+        self.swap_counts = torch.zeros(2, dtype=torch.int64, device=dev)
         self.state = DeviceChains(self.prob, starts, model_params.assemble_proposal_width(),
-                                  beta=self.betas[self._lo:self._lo + n],
+                                  beta=self.beta_all[self._lo:self._lo + n],
                                   individual_acceptance=individual_acceptance)
         status = self.state.init_likelihood()
         if int((status != 0).sum()):
             raise DispersionError("starting model has no dispersion curve")
         self._n_step = 0
         self._sync_host()
+
+    @property
+    def betas(self):
+        """Current beta of every replica (host copy)."""
+        return self.beta_all.cpu().numpy()
+
+    @property
+    def swap_acc(self):
+        return int(self.swap_counts[0])
+
+    @property
+    def swap_prop(self):
+        return int(self.swap_counts[1])
 
     def _sync_host(self):
         self._m_host = self.state.m.cpu().numpy()
@@ -136,7 +189,8 @@ class Inversion:
     @property
     def chains(self):
         self._sync_host()
-        return [_ChainView(self, i) for i in range(self.n_local)]
+        betas = self.betas
+        return [_ChainView(self, i, betas) for i in range(self.n_local)]
 
     # ------------------------------------------------------------------ output
     def _path(self, kind, chunk=None):
@@ -178,10 +232,15 @@ class Inversion:
     # ------------------------------------------------------------------ stepping
     def step_segment(self, idx, cauchy, u_acc, rotate=0, sample_prior=False, hist_every=0,
                      want_pred_hist=False, T=1.0):
-        """Run idx.shape[0] MH steps for every local chain on supplied draws."""
+        """Run idx.shape[0] MH steps for every local chain on supplied draws (numpy arrays, or
+        device tensors, which are used as they are)."""
         import torch
         dev = self.prob.device
-        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+
+        def t(a, dt):
+            if torch.is_tensor(a):
+                return a
+            return torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
         return self.state.steps(t(idx, torch.int32), t(cauchy, torch.float64),
                                 t(u_acc, torch.float64), T=T, rotate=rotate,
                                 sample_prior=sample_prior, hist_every=hist_every,
@@ -203,73 +262,69 @@ class Inversion:
         self.state.rot.copy_(torch.as_tensor(np.ascontiguousarray(U), device=dev))
         self.state.width.copy_(torch.as_tensor(np.sqrt(s), device=dev))
 
+    def _is_refresh(self, s):
+        return s >= self.n_burn + self.n_cov_chunk + 2 and s % self.n_cov_chunk == 0
+
+    def _run_segment(self, step, seg, idx, cz, xi, rotate_params, sample_prior):
+        """Outer steps step..step+seg-1 (seg * n_thin MH steps on the draws given, which begin at
+        this segment); at most the first of them refreshes the rotation matrix.  Returns the
+        outputs of the launches that recorded history (one record per outer step)."""
+        nt = self.n_thin
+        S = seg * nt
+        rot = 0
+        if rotate_params:
+            rot = L.ROT_ACCUMULATE | (0 if step < self.n_burn else L.ROT_FRAME)
+        lo = 0
+        outs = []
+        if rotate_params and self._is_refresh(step):
+            # covariance first, then the new rotation, then the proposal of this
+            # thin-iteration (src/inversion/model.py:183-193)
+            self.state.cov_accumulate()
+            self._refresh_rotation()
+            out0 = self.step_segment(idx[:1], cz[:1], xi[:1], rotate=L.ROT_FRAME,
+                                     sample_prior=sample_prior,
+                                     hist_every=1 if nt == 1 else 0, want_pred_hist=nt == 1)
+            lo = 1
+            if nt == 1:
+                outs.append(out0)
+        if S > lo:
+            # history after every n_thin-th step of the segment
+            kw = dict(rotate=rot, sample_prior=sample_prior, want_pred_hist=True)
+            if lo == 0:
+                outs.append(self.step_segment(idx[:S], cz[:S], xi[:S], hist_every=nt, **kw))
+            elif nt == 1:
+                outs.append(self.step_segment(idx[1:S], cz[1:S], xi[1:S], hist_every=1, **kw))
+            else:
+                # finish the first outer step, then the rest with regular spacing
+                outs.append(self.step_segment(idx[1:nt], cz[1:nt], xi[1:nt], hist_every=nt - 1,
+                                              **kw))
+                if S > nt:
+                    outs.append(self.step_segment(idx[nt:S], cz[nt:S], xi[nt:S], hist_every=nt,
+                                                  **kw))
+        return outs
+
     def random_walk(self, model_params, proposal_distribution, sample_prior=False,
                     rotate_params=False):
         """The main loop for n_mcmc steps (src/inversion/inversion.py:367-429)."""
-        import torch
         if proposal_distribution != "cauchy":
             raise NotImplementedError("only the 'cauchy' proposal is mirrored")
-        nt = self.n_thin
-        local_b1 = np.flatnonzero(self.betas[self._lo:self._lo + self.n_local] == 1)
+        if self.tempering:
+            return self._random_walk_tempered(rotate_params, sample_prior)
         rec = {}
         step = 0
         while step < self.n_mcmc:
-            # a segment ends at a chunk boundary, at a tempering sweep and before a step
-            # on which the rotation matrix is refreshed
+            # a segment ends at a chunk boundary and before a step on which the rotation matrix
+            # is refreshed
             seg = min(self.n_chunk - step % self.n_chunk, self.n_mcmc - step)
-            if self.n_chains > 1:
-                seg = 1
-            refresh = False
             if rotate_params:
-                def is_refresh(s):
-                    return s >= self.n_burn + self.n_cov_chunk + 2 and s % self.n_cov_chunk == 0
-                refresh = is_refresh(step)
-                nxt = next((s for s in range(step + 1, step + seg) if is_refresh(s)), None)
+                nxt = next((s for s in range(step + 1, step + seg) if self._is_refresh(s)), None)
                 if nxt is not None:
                     seg = nxt - step
                 if step < self.n_burn:
                     seg = min(seg, self.n_burn - step)
-            S = seg * nt
-            idx, cz, xi = self._draws(S)
-            rot = 0
-            if rotate_params:
-                rot = L.ROT_ACCUMULATE | (0 if step < self.n_burn else L.ROT_FRAME)
-            lo = 0
-            if refresh:
-                # covariance first, then the new rotation, then the proposal of this
-                # thin-iteration (src/inversion/model.py:183-193)
-                self.state.cov_accumulate()
-                self._refresh_rotation()
-                out0 = self.step_segment(idx[:1], cz[:1], xi[:1], rotate=L.ROT_FRAME,
-                                         sample_prior=sample_prior,
-                                         hist_every=1 if nt == 1 else 0, want_pred_hist=nt == 1)
-                lo = 1
-            outs = []
-            if lo == 1 and nt == 1:
-                outs.append(out0)
-            if S > lo:
-                # history after every n_thin-th step of the segment
-                if lo == 0:
-                    outs.append(self.step_segment(idx, cz, xi, rotate=rot,
-                                                  sample_prior=sample_prior, hist_every=nt,
-                                                  want_pred_hist=True))
-                elif nt == 1:
-                    outs.append(self.step_segment(idx[1:], cz[1:], xi[1:], rotate=rot,
-                                                  sample_prior=sample_prior, hist_every=1,
-                                                  want_pred_hist=True))
-                else:
-                    # finish the first outer step, then the rest with regular spacing
-                    outs.append(self.step_segment(idx[1:nt], cz[1:nt], xi[1:nt], rotate=rot,
-                                                  sample_prior=sample_prior, hist_every=nt - 1,
-                                                  want_pred_hist=True))
-                    if S > nt:
-                        outs.append(self.step_segment(idx[nt:], cz[nt:], xi[nt:], rotate=rot,
-                                                      sample_prior=sample_prior, hist_every=nt,
-                                                      want_pred_hist=True))
-            if self.n_chains > 1:
-                self.perform_tempering_swap()
-                local_b1 = np.flatnonzero(self.betas[self._lo:self._lo + self.n_local] == 1)
-            self._store(rec, outs, local_b1)
+            idx, cz, xi = self._draws(seg * self.n_thin)
+            outs = self._run_segment(step, seg, idx, cz, xi, rotate_params, sample_prior)
+            self._store(rec, outs)
             step += seg
             self._n_step = step
             if step % self.n_chunk == 0 or step == self.n_mcmc:
@@ -278,22 +333,57 @@ class Inversion:
                 rec = {}
         self._sync_host()
 
-    def _store(self, rec, outs, local_b1):
-        """Per-step records of the beta == 1 chains (src/inversion/inversion.py:431-487)."""
+    def _random_walk_tempered(self, rotate_params, sample_prior):
+        """Tempered run: per outer step n_thin MH steps of every replica, the all-gather of logL
+        and the exchange sweep, all enqueued on the stream; the host waits at chunk ends (and
+        where the rotation matrix is refreshed)."""
+        import torch
+        dev = self.prob.device
+        nt = self.n_thin
+        step = 0
+        while step < self.n_mcmc:
+            n_outer = min(self.n_chunk - step % self.n_chunk, self.n_mcmc - step)
+            # the draws of the whole chunk, uploaded once
+            idx, cz, xi = self._draws(n_outer * nt)
+            idx = torch.as_tensor(idx, device=dev)
+            cz = torch.as_tensor(cz, device=dev)
+            xi = torch.as_tensor(xi, device=dev)
+            u_swap = torch.as_tensor(
+                self.swap_rng.rand(n_outer, self.n_ladders, self.n_temps - 1), device=dev)
+            rec = {}
+            beta_hist = torch.empty((n_outer, self.n_local), dtype=torch.float64, device=dev)
+            for j in range(n_outer):
+                a, b = j * nt, (j + 1) * nt
+                outs = self._run_segment(step + j, 1, idx[a:b], cz[a:b], xi[a:b], rotate_params,
+                                         sample_prior)
+                self.perform_tempering_swap(u_swap[j])
+                beta_hist[j] = self.state.beta
+                self._store(rec, outs)
+            rec["beta"] = [beta_hist]
+            step += n_outer
+            self._n_step = step
+            if self.out_filename is not None:
+                self._write_chunk((step - 1) // self.n_chunk, self._finish(rec))
+        self._sync_host()
+
+    def _store(self, rec, outs):
+        """Per-step records (src/inversion/inversion.py:431-487) of every chain of this process;
+        copied to the host when the chunk is finished."""
         for o in outs:
             if "hist_m" not in o:
                 continue
-            sel = local_b1
-            rec.setdefault("model_params", []).append(o["hist_m"][:, sel].cpu().numpy())
-            rec.setdefault("logL", []).append(o["hist_logL"][:, sel].cpu().numpy())
+            rec.setdefault("model_params", []).append(o["hist_m"])
+            rec.setdefault("logL", []).append(o["hist_logL"])
             if "hist_pred" in o:
-                rec.setdefault("data_pred", []).append(o["hist_pred"][:, sel].cpu().numpy())
-            rec["chain"] = self._lo + sel
+                rec.setdefault("data_pred", []).append(o["hist_pred"])
 
     def _finish(self, rec):
+        import torch
         out = {}
         for k, v in rec.items():
-            out[k] = np.concatenate(v, axis=0) if isinstance(v, list) else np.asarray(v)
+            v = [x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x) for x in v]
+            out[k] = np.concatenate(v, axis=0)
+        out["chain"] = self._lo + np.arange(self.n_local)
         cnt = self.state.counters.cpu().numpy()
         tot = np.maximum(cnt[:, 0] + cnt[:, 1], 1)
         out["acc_rate"] = cnt[:, 0] / tot
@@ -308,29 +398,36 @@ class Inversion:
 
     # ------------------------------------------------------------------ tempering
     def gather_logL(self):
-        """logL of all n_chains chains: the one collective of the sampler."""
-        return gather_chain_values(self.state.logL, self.n_chains, self.world)
+        """logL of all replicas on the device: the one collective of the sampler (an all-gather
+        of n_local float64 per rank; RCCL on GPUs)."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return self.state.logL
+        dist.all_gather_into_tensor(self.logL_all, self.state.logL)
+        return self.logL_all
 
-    def perform_tempering_swap(self):
-        """Exchange move between temperature neighbours (src/inversion/inversion.py:560-596).
+    def perform_tempering_swap(self, u=None):
+        """Exchange move between temperature neighbours of every ladder
+        (src/inversion/inversion.py:560-596) on the device.
 
-        Every rank evaluates all n_chains - 1 adjacent pairs from the gathered logL and the
-        shared uniform stream, so the decisions are identical everywhere; betas are swapped,
-        states never move.
+        Every rank runs the sweep over all ladders from the gathered logL and the shared
+        uniforms u [n_ladders, n_temps-1] (drawn from swap_rng when not given), so the betas
+        stay identical everywhere; betas are swapped, states never move.  Nothing here waits
+        for the device.
         """
         import torch
-        logL = self.gather_logL()
-        xi = self.swap_rng.rand(self.n_chains - 1)
-        self.betas, acc, prop = tempering_sweep(self.betas, logL, xi)
-        self.swap_acc += acc
-        self.swap_prop += prop
-        mine = self.betas[self._lo:self._lo + self.n_local]
-        self.state.beta.copy_(torch.as_tensor(mine, device=self.prob.device))
+        from ..engine import tempering_sweep
+        if u is None:
+            u = torch.as_tensor(self.swap_rng.rand(self.n_ladders, self.n_temps - 1),
+                                device=self.prob.device)
+        tempering_sweep(self.gather_logL(), self.beta_all, u.contiguous(), self.n_temps,
+                        self.n_ladders, self.rung_stride, self.ladder_stride, self.swap_counts)
 
 
 def gather_chain_values(local, n_total, world):
-    """All-gather of a per-chain float64 vector (a torch tensor) over the ranks; every rank owns
-    a contiguous block of n_total / world chains.  RCCL ("nccl") on GPUs, gloo on the host."""
+    """All-gather of a per-chain float64 vector (a torch tensor) over the ranks to the host;
+    every rank owns a contiguous block of n_total / world chains.  RCCL ("nccl") on GPUs, gloo
+    on the host."""
     import torch
     import torch.distributed as dist
     if world == 1:
@@ -341,23 +438,3 @@ def gather_chain_values(local, n_total, world):
     full = torch.empty(n_total, dtype=torch.float64, device=local.device)
     dist.all_gather_into_tensor(full, local)
     return full.cpu().numpy()
-
-
-def tempering_sweep(betas, logL, xi):
-    """One sweep over adjacent pairs; returns (betas, n_accepted, n_proposed) counted, as the
-    reference counts them, for pairs that involve a beta == 1 chain."""
-    betas = np.array(betas, dtype=float)
-    acc = prop = 0
-    for ind in range(len(betas) - 1):
-        b1, b2 = betas[ind], betas[ind + 1]
-        if b1 != b2:
-            logratio = (b2 - b1) * (logL[ind] - logL[ind + 1])
-            with np.errstate(over="ignore"):
-                ok = xi[ind] <= np.exp(logratio)
-            if ok:
-                betas[ind], betas[ind + 1] = b2, b1
-                if b1 == 1 or b2 == 1:
-                    acc += 1
-            if b1 == 1 or b2 == 1:
-                prop += 1
-    return betas, acc, prop

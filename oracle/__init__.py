@@ -205,3 +205,37 @@ def cov_accumulate(state):
 def set_threads(n):
     """Threads orc_mh_step spreads the chains over (1 = scalar)."""
     lib().orc_set_threads(int(n))
+
+
+def tempering_sweep(betas, logL, xi, n_temps=None, n_ladders=1, rung_stride=1, ladder_stride=None):
+    """One exchange sweep of Inversion.perform_tempering_swap
+    (src/inversion/inversion.py:560-596) on the host, for n_ladders temperature ladders of
+    n_temps rungs; replica (l, t) is element l*ladder_stride + t*rung_stride.  Adjacent pairs
+    in order, xi <= exp((beta2 - beta1)(logL1 - logL2)) (:578-586); an accepted exchange swaps
+    the betas (the working version of the rule: the reference decides and then changes
+    nothing).  xi is [n_ladders, n_temps-1].  Returns (betas, accepted, proposed), the counts
+    being those of pairs with a beta == 1 member (:588-596).  The default is the reference's
+    one flat ladder over all chains."""
+    betas = np.array(betas, dtype=float)
+    if n_temps is None:
+        n_temps = len(betas)
+    if ladder_stride is None:
+        ladder_stride = n_temps
+    xi = np.asarray(xi, dtype=float).reshape(n_ladders, max(n_temps - 1, 0))
+    acc = prop = 0
+    for l in range(n_ladders):
+        for t in range(n_temps - 1):
+            i1 = l * ladder_stride + t * rung_stride
+            i2 = i1 + rung_stride
+            b1, b2 = betas[i1], betas[i2]
+            if b1 != b2:
+                logratio = (b2 - b1) * (logL[i1] - logL[i2])
+                with np.errstate(over="ignore"):
+                    ok = xi[l, t] <= np.exp(logratio)
+                if ok:
+                    betas[i1], betas[i2] = b2, b1
+                    if b1 == 1 or b2 == 1:
+                        acc += 1
+                if b1 == 1 or b2 == 1:
+                    prop += 1
+    return betas, acc, prop

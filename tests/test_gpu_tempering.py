@@ -1,0 +1,118 @@
+"""Parallel tempering on the device: the exchange sweep kernel against its host restatement, and
+a tempered Inversion.random_walk (8 temperatures x 16 ladders) against a host simulation that
+drives the oracle's MH step and the oracle's sweep with the same draws."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mp(n_layers):
+    from mcmc_amd.inversion import DispersionCurveParams
+    bounds = {"depth": np.array([0.001, 0.15]), "vel_s": np.array([0.1, 2.0])}
+    return DispersionCurveParams(n_layers, bounds, {"depth": 0.05, "vel_s": 0.05}, 1.75)
+
+
+@pytest.mark.parametrize("layout", ["ladder", "rung"])
+@pytest.mark.parametrize("n_temps,n_ladders", [(64, 128), (8, 16), (2, 1), (5, 3)])
+def test_sweep_kernel_matches_host_restatement(oracle, layout, n_temps, n_ladders):
+    """Betas (bit for bit) and the swap counters after several sweeps, full size of the
+    64 x 128 configuration included."""
+    import torch
+    from mcmc_amd.engine import tempering_sweep
+    from mcmc_amd.inversion.inversion import ladder_layout
+    rng = np.random.default_rng(n_temps * 1000 + n_ladders)
+    rs, ls = ladder_layout(n_temps, n_ladders, layout)
+    R = n_temps * n_ladders
+    ladder = np.ones(n_temps)
+    nf = int(np.ceil(n_temps / 4))
+    ladder[nf:] = 1.0 / 1.15 ** np.arange(nf, n_temps)
+    betas = np.empty(R)
+    for l in range(n_ladders):
+        betas[l * ls + np.arange(n_temps) * rs] = ladder
+    dev = torch.device("cuda")
+    beta_d = torch.tensor(betas, device=dev)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    acc = prop = 0
+    for sweep in range(6):
+        logL = rng.normal(-60.0, 15.0, R)
+        u = rng.uniform(size=(n_ladders, n_temps - 1))
+        tempering_sweep(torch.tensor(logL, device=dev), beta_d, torch.tensor(u, device=dev),
+                        n_temps, n_ladders, rs, ls, counts)
+        betas, a, p = oracle.tempering_sweep(betas, logL, u, n_temps, n_ladders, rs, ls)
+        acc, prop = acc + a, prop + p
+        np.testing.assert_array_equal(beta_d.cpu().numpy(), betas)
+    assert counts.tolist() == [acc, prop] and prop > 0
+    # betas were exchanged, and only inside their ladder
+    pos = np.arange(n_ladders)[:, None] * ls + np.arange(n_temps)[None, :] * rs
+    np.testing.assert_array_equal(np.sort(betas[pos], axis=1)[:, ::-1],
+                                  np.tile(ladder, (n_ladders, 1)))
+
+
+@pytest.mark.parametrize("layout", ["ladder", "rung"])
+def test_tempered_random_walk_matches_host_simulation(oracle, tmp_path, layout):
+    """8 temperatures x 16 ladders, 12 outer steps of 3 MH steps with a sweep after each: states,
+    betas and the recorded history equal those of the oracle driven with the same draws."""
+    from mcmc_amd.inversion import Data, Inversion
+    nl, P, NT, NLAD = 3, 20, 8, 16
+    R = NT * NLAD
+    mp = _mp(nl)
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    true_m = np.array([0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0])
+    rng = np.random.default_rng(2)
+    obs = oracle.forward(true_m, nl, 1.75, periods)[1] + 0.025 * rng.standard_normal(P)
+    noise = {"std": 0.025}
+    data = Data(periods, obs, "normal", noise)
+    data.model_true = true_m
+    n_mcmc, n_thin, n_chunk = 12, 3, 6
+    np.random.seed(9)
+    inv = Inversion(data, mp, "normal", noise, n_burn=0, n_chunk=n_chunk, n_mcmc=n_mcmc,
+                    n_thin=n_thin, n_chains=NLAD, n_temps=NT, beta_spacing_factor=1.3,
+                    set_starting_model=True, out_filename="pt", out_dir=str(tmp_path) + "/",
+                    swap_seed=4, layout=layout)
+    assert inv.n_replicas == R and inv.tempering
+    betas = inv.betas.copy()
+    start_betas = betas.copy()
+    drawn = []
+    orig = inv._draws
+
+    def record(S):
+        d = orig(S)
+        drawn.append(d)
+        return d
+    inv._draws = record
+    inv.random_walk(mp, "cauchy")
+
+    # the same run on the host
+    swap_rng = np.random.RandomState(4)
+    starts = np.tile(true_m, (R, 1))
+    _, vel, _ = oracle.forward_batch(starts, nl, 1.75, periods)
+    logL0 = np.array([oracle.loglik(obs, v, "normal", noise) for v in vel])
+    st = oracle.ChainState(starts, logL0, vel, 0.05, mp.assemble_param_bounds())
+    hist_m, hist_beta = [], []
+    acc = prop = 0
+    for chunk, (idx, cz, xi) in enumerate(drawn):
+        n_outer = idx.shape[0] // n_thin
+        assert n_outer == n_chunk
+        u_swap = swap_rng.rand(n_outer, NLAD, NT - 1)
+        for j in range(n_outer):
+            for s in range(j * n_thin, (j + 1) * n_thin):
+                oracle.mh_step(st, idx[s], cz[s], xi[s], nl, 1.75, periods, obs, "normal", noise,
+                               beta=betas)
+            betas, a, p = oracle.tempering_sweep(betas, st.logL, u_swap[j], NT, NLAD,
+                                                 inv.rung_stride, inv.ladder_stride)
+            acc, prop = acc + a, prop + p
+            hist_m.append(st.m.copy())
+            hist_beta.append(betas.copy())
+    np.testing.assert_array_equal(inv.betas, betas)
+    np.testing.assert_array_equal(inv.state.m.cpu().numpy(), st.m)
+    np.testing.assert_allclose(inv.state.logL.cpu().numpy(), st.logL, rtol=1e-9)
+    assert (inv.swap_acc, inv.swap_prop) == (acc, prop) and acc > 0
+    assert (betas != start_betas).any()
+    import glob
+    files = sorted(glob.glob(str(tmp_path) + "/results-pt-*.npz"))
+    assert len(files) == n_mcmc // n_chunk
+    got_m = np.concatenate([np.load(f)["model_params"] for f in files])
+    got_b = np.concatenate([np.load(f)["beta"] for f in files])
+    np.testing.assert_array_equal(got_m, np.array(hist_m))
+    np.testing.assert_array_equal(got_b, np.array(hist_beta))

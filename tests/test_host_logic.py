@@ -96,51 +96,110 @@ def test_get_betas_reference_and_fixed():
         assert (fixed[want == 0] == 1).all()
 
 
-def test_tempering_sweep_rule():
-    from mcmc_amd.inversion.inversion import tempering_sweep
+def test_tempering_sweep_rule(oracle):
     betas = np.array([1.0, 1.0, 0.5, 0.25])
     logL = np.array([-10.0, -12.0, -3.0, -50.0])
     # pair (0,1): equal betas -> skipped.  pair (1,2): logratio=(0.5-1)(-12+3)=4.5 -> accept.
     # pair (2,3) now holds betas (1.0, 0.25): logratio=(0.25-1)(-3+50) < 0, xi=0.9 -> reject.
-    b, acc, prop = tempering_sweep(betas, logL, np.array([0.3, 0.99, 0.9]))
+    b, acc, prop = oracle.tempering_sweep(betas, logL, np.array([0.3, 0.99, 0.9]))
     np.testing.assert_array_equal(b, [1.0, 0.5, 1.0, 0.25])
     assert (acc, prop) == (1, 2)
+    # the same ladder twice, once per layout: exchanges stay inside a ladder
+    from mcmc_amd.inversion.inversion import ladder_layout
+    xi = np.array([[0.3, 0.99, 0.9], [0.3, 0.99, 0.9]])
+    for layout in ("ladder", "rung"):
+        rs, ls = ladder_layout(4, 2, layout)
+        pos = (np.arange(2)[:, None] * ls + np.arange(4)[None, :] * rs).ravel()
+        bb, ll = np.empty(8), np.empty(8)
+        bb[pos], ll[pos] = np.tile(betas, 2), np.tile(logL, 2)
+        out, acc, prop = oracle.tempering_sweep(bb, ll, xi, 4, 2, rs, ls)
+        np.testing.assert_array_equal(out[pos], np.tile([1.0, 0.5, 1.0, 0.25], 2))
+        assert (acc, prop) == (2, 4)
 
 
-def _rank_main(rank, world, port, ret):
+def test_replica_betas_per_ladder():
+    """64 temperatures x 128 ladders: every ladder holds the ladder of get_betas(64), the
+    coldest quarter at beta = 1, nothing underflows; 1024 replicas per rank of 8."""
+    from mcmc_amd.inversion.inversion import Inversion, ladder_layout
+    for layout in ("ladder", "rung"):
+        inv = Inversion.__new__(Inversion)
+        inv.n_chains, inv.reference_betas = 128, False
+        inv.n_temps, inv.n_ladders, inv.n_replicas = 64, 128, 64 * 128
+        inv.rung_stride, inv.ladder_stride = ladder_layout(64, 128, layout)
+        b = inv.replica_betas(1.15)
+        ladder = inv.get_betas(1.15, 64)
+        assert ladder.min() > 1e-4 and (ladder[:16] == 1).all() and (np.diff(ladder[15:]) < 0).all()
+        grid = b[np.arange(128)[:, None] * inv.ladder_stride + np.arange(64)[None, :] * inv.rung_stride]
+        assert (grid == ladder[None, :]).all()
+        assert b.size == 8192 and b.size // 8 == 1024
+
+
+def _rank_main(rank, world, port, ret, tmp):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from mcmc_amd.inversion.inversion import gather_chain_values, tempering_sweep
-    n = 16
+    import oracle
+    from mcmc_amd.inversion.inversion import Inversion, gather_chain_values, ladder_layout
+    n_temps, n_ladders = 4, 6
+    n = n_temps * n_ladders
     rng = np.random.RandomState(3)           # same stream on every rank
     all_logL = rng.normal(-100, 20, (5, n))  # 5 sweeps
-    betas = 1.0 / 1.3 ** np.arange(n)
-    swap_rng = np.random.RandomState(0)
-    per = n // world
-    for sweep in range(5):
-        local = torch.tensor(all_logL[sweep, rank * per:(rank + 1) * per])
-        full = gather_chain_values(local, n, world)
-        betas, _, _ = tempering_sweep(betas, full, swap_rng.rand(n - 1))
-    ret[rank] = betas.tolist()
+    out = {}
+    for layout in ("ladder", "rung"):
+        rs, ls = ladder_layout(n_temps, n_ladders, layout)
+        inv = Inversion.__new__(Inversion)
+        inv.n_chains, inv.reference_betas = n_ladders, False
+        inv.n_temps, inv.n_ladders, inv.n_replicas = n_temps, n_ladders, n
+        inv.rung_stride, inv.ladder_stride = rs, ls
+        betas = inv.replica_betas(1.3)
+        swap_rng = np.random.RandomState(0)
+        per = n // world
+        for sweep in range(5):
+            local = torch.tensor(all_logL[sweep, rank * per:(rank + 1) * per])
+            full = gather_chain_values(local, n, world)
+            betas, _, _ = oracle.tempering_sweep(betas, full, swap_rng.rand(n_ladders, n_temps - 1),
+                                                 n_temps, n_ladders, rs, ls)
+        out[layout] = betas.tolist()
+    ret[rank] = out
+    # every rank writes the records of its own chains: no two ranks name the same file
+    inv = Inversion.__new__(Inversion)
+    inv.rank, inv.world, inv.out_dir, inv.out_filename = rank, world, tmp + "/", "run"
+    inv._write_chunk(0, {"model_params": np.full((2, 3), float(rank))})
+    dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_tempering_two_ranks_gloo():
-    """world_size 2 over gloo: both ranks reach the betas of the single-process sweep."""
+def test_sharded_tempering_two_ranks_gloo(oracle, tmp_path):
+    """world_size 2 over gloo, 4 temperatures x 6 ladders in both layouts: both ranks reach the
+    betas of the single-process sweeps; and both write their chunk of results."""
     import torch.multiprocessing as mp
-    from mcmc_amd.inversion.inversion import tempering_sweep
+    from mcmc_amd.inversion.inversion import Inversion, ladder_layout
     world, port = 2, 29500 + os.getpid() % 2000
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_rank_main, args=(world, port, ret), nprocs=world, join=True)
-    n = 16
+    mp.spawn(_rank_main, args=(world, port, ret, str(tmp_path)), nprocs=world, join=True)
+    n_temps, n_ladders = 4, 6
+    n = n_temps * n_ladders
     rng = np.random.RandomState(3)
     all_logL = rng.normal(-100, 20, (5, n))
-    betas = 1.0 / 1.3 ** np.arange(n)
-    swap_rng = np.random.RandomState(0)
-    for sweep in range(5):
-        betas, _, _ = tempering_sweep(betas, all_logL[sweep], swap_rng.rand(n - 1))
-    assert ret[0] == ret[1] == betas.tolist()
-    assert sorted(ret[0]) == sorted((1.0 / 1.3 ** np.arange(n)).tolist())  # a permutation
+    for layout in ("ladder", "rung"):
+        rs, ls = ladder_layout(n_temps, n_ladders, layout)
+        inv = Inversion.__new__(Inversion)
+        inv.n_chains, inv.reference_betas = n_ladders, False
+        inv.n_temps, inv.n_ladders, inv.n_replicas = n_temps, n_ladders, n
+        inv.rung_stride, inv.ladder_stride = rs, ls
+        start = inv.replica_betas(1.3)
+        betas = start.copy()
+        swap_rng = np.random.RandomState(0)
+        for sweep in range(5):
+            betas, _, _ = oracle.tempering_sweep(betas, all_logL[sweep],
+                                                 swap_rng.rand(n_ladders, n_temps - 1), n_temps,
+                                                 n_ladders, rs, ls)
+        assert ret[0][layout] == ret[1][layout] == betas.tolist()
+        assert (betas != start).any()
+        pos = np.arange(n_ladders)[:, None] * ls + np.arange(n_temps)[None, :] * rs
+        np.testing.assert_array_equal(np.sort(betas[pos], axis=1), np.sort(start[pos], axis=1))
+    for r in range(world):
+        f = np.load(str(tmp_path) + f"/results-run-r{r}-00000.npz")
+        assert (f["model_params"] == float(r)).all()
