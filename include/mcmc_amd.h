@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MHD_ABI_VERSION 3
+#define MHD_ABI_VERSION 4
 
 #define MHD_OK 0
 #define MHD_EINVAL (-22) /* bad argument (size beyond a compiled limit, NULL pointer) */
@@ -56,6 +56,7 @@ extern "C" {
 #define MHD_LOVE 1
 #define MHD_PHASE 0
 #define MHD_GROUP 1
+#define MHD_PHASE_AND_GROUP 2 /* both curves as one datum of length 2P: [phase, group] */
 #define MHD_NORMAL 0
 #define MHD_ASYM_LAPLACE 1
 
@@ -75,23 +76,36 @@ extern "C" {
 typedef struct mhd_problem {
     int32_t n_layers;   /* finite layers; NP = 2*n_layers+1 parameters =
                            [n_layers interface depths, n_layers+1 vs]   */
-    int32_t n_periods;  /* P */
+    int32_t n_periods;  /* P; the data vectors (obs, pred, noise) have ND = P entries, or
+                           2P for MHD_PHASE_AND_GROUP (then P <= MHD_MAX_PERIODS / 2)  */
     int32_t wave;       /* MHD_RAYLEIGH | MHD_LOVE  (disba wave=)        */
     int32_t mode;       /* 0 = fundamental          (disba mode=)        */
-    int32_t itype;      /* MHD_PHASE | MHD_GROUP                         */
+    int32_t itype;      /* MHD_PHASE | MHD_GROUP | MHD_PHASE_AND_GROUP           */
     int32_t noise_dist; /* MHD_NORMAL | MHD_ASYM_LAPLACE                 */
-    int32_t n_noise_a;  /* 1 or P: length of noise_a                     */
-    int32_t n_noise_b;  /* 1 or P: length of noise_b                     */
+    int32_t n_noise_a;  /* 1 or ND: length of noise_a                    */
+    int32_t n_noise_b;  /* 1 or ND: length of noise_b                    */
     double vpvs;        /* vp = vs * vpvs   (model_params.py:95-97)      */
     double dc;          /* bracketing step, disba default 0.005 km/s     */
     double dt;          /* group-velocity period offset, disba 0.025     */
     const double *periods; /* device [P], ascending (src/main.py:29)     */
-    const double *obs;     /* device [P] data_obs; may be NULL for forward-only calls */
+    const double *obs;     /* device [ND] data_obs; may be NULL for forward-only calls */
     const double *noise_a; /* device: std (normal) | lambd_scale*lambd clipped at
                               lambd_max (asym-laplace, model.py:438-440)  */
     const double *noise_b; /* device: kappa (asym-laplace) or NULL        */
     const double *bounds;  /* device [NP,3] = lo, hi, hi-lo
                               (model_params.py:104-126); NULL for forward-only */
+    /* Models of different layer counts in one batch (the reference names a
+       trans-dimensional parameterisation, README.md:16, without code for it; the
+       layout is this library's): device int32 [B] or NULL.  Model b has
+       n_layers_b[b] <= n_layers finite layers; its row of NP = 2*n_layers+1
+       parameters keeps the padded positions: interface depths in slots
+       0..n_layers_b[b]-1, vs of the layers in slots n_layers..n_layers+n_layers_b[b]-1
+       and of the half-space in slot n_layers+n_layers_b[b]; the other slots are
+       ignored and never change.  idx[s,b] of mhd_mh_steps must name a used slot;
+       bounds, width and the per-parameter counters are indexed by slot.  Not
+       available together with the rotate flags (MHD_EINVAL).  The array belongs
+       to the batch of the call it is passed with (B models / B chains). */
+    const int32_t *n_layers_b;
     /* Tuning and testing switches without a counterpart in the reference; 0 picks
        the default.  Every setting returns the same curves and the same chains. */
     int32_t search;     /* root search of the forward model: 2 (default) = period-

@@ -8,17 +8,18 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmcmc_amd.so")
+# (MCMC_AMD_LIB: another build of the same library, for A/B measurements)
+LIB_PATH = os.environ.get("MCMC_AMD_LIB") or os.path.join(_HERE, "lib", "libmcmc_amd.so")
 
 c_int32, c_double, c_void_p = ctypes.c_int32, ctypes.c_double, ctypes.c_void_p
 
 ST_OK, ST_BOUNDS, ST_PHYSICS, ST_NOROOT, ST_ZERODIV = 0, 1, 2, 3, 4
 RAYLEIGH, LOVE = 0, 1
-PHASE, GROUP = 0, 1
+PHASE, GROUP, PHASE_AND_GROUP = 0, 1, 2
 NORMAL, ASYM_LAPLACE = 0, 1
 ROT_ACCUMULATE, ROT_FRAME = 1, 2
 MAX_LAYERS, MAX_PERIODS = 15, 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = (
     "mhd_abi_version",
@@ -43,7 +44,8 @@ class Problem(ctypes.Structure):
         ("itype", c_int32), ("noise_dist", c_int32), ("n_noise_a", c_int32),
         ("n_noise_b", c_int32), ("vpvs", c_double), ("dc", c_double), ("dt", c_double),
         ("periods", c_void_p), ("obs", c_void_p), ("noise_a", c_void_p), ("noise_b", c_void_p),
-        ("bounds", c_void_p), ("search", c_int32), ("candidates", c_int32),
+        ("bounds", c_void_p), ("n_layers_b", c_void_p), ("search", c_int32),
+        ("candidates", c_int32),
     ]
 
 

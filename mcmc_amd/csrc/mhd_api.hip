@@ -35,7 +35,10 @@ int check_problem(const mhd_problem_t* p, bool need_data)
     if (p->n_periods < 1 || p->n_periods > MHD_MAX_PERIODS)
         return fail(MHD_EINVAL, "n_periods outside 1..MHD_MAX_PERIODS");
     if (p->wave != MHD_RAYLEIGH && p->wave != MHD_LOVE) return fail(MHD_EINVAL, "bad wave");
-    if (p->itype != MHD_PHASE && p->itype != MHD_GROUP) return fail(MHD_EINVAL, "bad itype");
+    if (p->itype != MHD_PHASE && p->itype != MHD_GROUP && p->itype != MHD_PHASE_AND_GROUP)
+        return fail(MHD_EINVAL, "bad itype");
+    if (p->itype == MHD_PHASE_AND_GROUP && 2 * p->n_periods > MHD_MAX_PERIODS)
+        return fail(MHD_EINVAL, "phase and group together: 2 * n_periods beyond MHD_MAX_PERIODS");
     if (p->mode < 0 || p->mode > 64) return fail(MHD_EINVAL, "bad mode");
     if (!(p->dc > 0.0) && !(p->dc < 0.0)) return fail(MHD_EINVAL, "dc must be non-zero");
     if (!p->periods) return fail(MHD_EINVAL, "periods is NULL");
@@ -50,10 +53,10 @@ int check_problem(const mhd_problem_t* p, bool need_data)
             return fail(MHD_EINVAL, "bad noise_dist");
         if (p->noise_dist == MHD_ASYM_LAPLACE && !p->noise_b)
             return fail(MHD_EINVAL, "asym-laplace needs noise_b (kappa)");
-        if ((p->n_noise_a != 1 && p->n_noise_a != p->n_periods) ||
-            (p->noise_dist == MHD_ASYM_LAPLACE && p->n_noise_b != 1 &&
-             p->n_noise_b != p->n_periods))
-            return fail(MHD_EINVAL, "noise arrays must have length 1 or n_periods");
+        const int nd = data_length(*p);
+        if ((p->n_noise_a != 1 && p->n_noise_a != nd) ||
+            (p->noise_dist == MHD_ASYM_LAPLACE && p->n_noise_b != 1 && p->n_noise_b != nd))
+            return fail(MHD_EINVAL, "noise arrays must have length 1 or that of the data");
     }
     return MHD_OK;
 }
@@ -61,6 +64,14 @@ int check_problem(const mhd_problem_t* p, bool need_data)
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
+
+// Finite layers of model ib of the batch (see mhd_problem_t.n_layers_b).
+__device__ __forceinline__ int layers_of(const mhd_problem_t& p, int ib)
+{
+    if (!p.n_layers_b) return p.n_layers;
+    const int n = p.n_layers_b[ib];
+    return n < 1 ? 1 : (n > p.n_layers ? p.n_layers : n);
+}
 
 __global__ __launch_bounds__(64) MHD_REGS void secular_kernel(mhd_problem_t p, const double* params, int B,
                                                      const int32_t* chain, const int32_t* period,
@@ -77,7 +88,7 @@ __global__ __launch_bounds__(64) MHD_REGS void secular_kernel(mhd_problem_t p, c
     const int ib = chain[q];
     if (lane < NP) m[lane] = params[(size_t)ib * NP + lane];
     __syncthreads();
-    build_layer_table(T, m, p.n_layers, p.vpvs, lane);
+    build_layer_table(T, m, layers_of(p, ib), p.vpvs, lane, p.n_layers);
     const double omega = TWOPI / p.periods[period[q]];
     const double d = secular(T, p.wave, omega, c[q]);
     if (lane == 0) delta[q] = d;
@@ -95,19 +106,19 @@ __global__ __launch_bounds__(64) MHD_REGS void forward_kernel(mhd_problem_t p, c
     __shared__ double scratch[2 * MAXP];
     const int ib = blockIdx.x;
     const int lane = threadIdx.x;
-    const int NP = 2 * p.n_layers + 1, P = p.n_periods;
+    const int NP = 2 * p.n_layers + 1, P = p.n_periods, ND = data_length(p);
     if (lane < NP) m[lane] = params[(size_t)ib * NP + lane];
     for (int k = lane; k < P; k += 64) t[k] = p.periods[k];
     __syncthreads();
-    build_layer_table(T, m, p.n_layers, p.vpvs, lane);
+    build_layer_table(T, m, layers_of(p, ib), p.vpvs, lane, p.n_layers);
     EvalCount cnt = {0, 0};
     const int st = (search == 2)
                        ? forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, out,
-                                           scratch, cnt, 0, t, 0)
+                                           scratch, cnt, 0, t, t, 0)
                        : forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, out, scratch,
                                       cnt);
     __syncthreads();
-    for (int k = lane; k < P; k += 64) vel[(size_t)ib * P + k] = (st == MHD_ST_OK) ? out[k] : 0.0;
+    for (int k = lane; k < ND; k += 64) vel[(size_t)ib * ND + k] = (st == MHD_ST_OK) ? out[k] : 0.0;
     if (lane == 0) {
         status[ib] = st;
         if (n_evals) {
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(64) void loglik_kernel(mhd_problem_t p, const doubl
     __shared__ double term[MAXP];
     const int ib = blockIdx.x;
     const int lane = threadIdx.x;
-    const int P = p.n_periods;
+    const int P = data_length(p);
     for (int k = lane; k < P; k += 64) pr[k] = pred[(size_t)ib * P + k];
     __syncthreads();
     const double l = loglik_wave(p, pr, term, lane);
@@ -179,6 +190,15 @@ __device__ __forceinline__ void hint_limit_update(float* limit, int kk, double c
     if (hinted == 2) limit[kk] = fmaxf(HLIM_SHRINK * (float)fabs(cz), 0.01f);
 }
 
+// Chains whose curves the predictor keeps getting wrong although it has the chain's current
+// curve to go by (densely spaced modes: the sequential search hops between branches): a curve
+// that needed this many repairs moves the chain to the period-by-period predictor, up to this level
+#ifndef HINTED_MAX_LEVEL
+#define HINTED_MAX_LEVEL 0
+#endif
+#ifndef HINTED_TROUBLE_MIN
+#define HINTED_TROUBLE_MIN 3
+#endif
 struct SearchPolicy {
     int level, left;
     int max_level;  // 3, or 0 where the predictor has the chain's current curve to go by: there
@@ -206,13 +226,19 @@ struct SearchPolicy {
 struct ProposalFrame {
     const double *lo, *hi, *rg, *wid;  // LDS copies of the bounds and proposal widths
     const double* R;                   // rotation matrix of the chain, or nullptr
-    int nl, NP;
+    int nl, NP;                        // finite layers of THIS chain; slots of a row
+    int nlmax;                         // slot of the first layer's vs = (NP - 1) / 2
+    // the slots this chain's model uses (all of them unless the batch mixes layer counts)
+    __device__ bool used(int slot) const
+    {
+        return slot < nl || (slot >= nlmax && slot <= nlmax + nl);
+    }
 };
 
 __device__ inline int propose_wave(const ProposalFrame& f, const double* mn, int kk, double cz,
                                    double* test, double* tmp, int lane)
 {
-    const int nl = f.nl, NP = f.NP;
+    const int nl = f.nl, NP = f.NP, vs_at = f.nlmax;
     if (f.R) {
         const double* R = f.R;
         if (lane < NP) {
@@ -239,7 +265,7 @@ __device__ inline int propose_wave(const ProposalFrame& f, const double* mn, int
     int rank = 0;
     if (lane < nl) {
         dep = test[lane];
-        vsl = test[nl + lane];
+        vsl = test[vs_at + lane];
         for (int j = 0; j < nl; ++j) {
             const double dj = test[j];
             rank += (dj < dep) || (dj == dep && j < lane);
@@ -248,12 +274,12 @@ __device__ inline int propose_wave(const ProposalFrame& f, const double* mn, int
     wave_sync();
     if (lane < nl) {
         test[rank] = dep;
-        test[nl + rank] = vsl;
+        test[vs_at + rank] = vsl;
     }
     wave_sync();
 
     bool inb = true;
-    if (lane < NP) inb = (test[lane] >= f.lo[lane]) && (test[lane] <= f.hi[lane]);
+    if (lane < NP && f.used(lane)) inb = (test[lane] >= f.lo[lane]) && (test[lane] <= f.hi[lane]);
     return (__ballot(!inb) != 0ull) ? MHD_ST_BOUNDS : MHD_ST_OK;
 }
 
@@ -293,7 +319,8 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
 
     const int ib = blockIdx.x;
     const int lane = threadIdx.x;
-    const int nl = p.n_layers, NP = 2 * nl + 1, P = p.n_periods;
+    const int nlmax = p.n_layers, NP = 2 * nlmax + 1, P = p.n_periods, ND = data_length(p);
+    const int nl = layers_of(p, ib);
 
     if (lane < NP) {
         m[lane] = ch.m[(size_t)ib * NP + lane];
@@ -303,14 +330,12 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
         wid[lane] = ch.width[(size_t)ib * NP + lane];
         hlim[lane] = (float)HINT_SECANT_CAUCHY;
     }
-    for (int k = lane; k < P; k += 64) {
-        t[k] = p.periods[k];
-        pred[k] = ch.pred[(size_t)ib * P + k];
-    }
+    for (int k = lane; k < P; k += 64) t[k] = p.periods[k];
+    for (int k = lane; k < ND; k += 64) pred[k] = ch.pred[(size_t)ib * ND + k];
     double logL = ch.logL[ib];
     const double beta = ch.beta ? ch.beta[ib] : 1.0;
     const double* R = (rotate & MHD_ROT_FRAME) ? ch.rot + (size_t)ib * NP * NP : nullptr;
-    const ProposalFrame frame = {lo, hi, rg, wid, R, nl, NP};
+    const ProposalFrame frame = {lo, hi, rg, wid, R, nl, NP, nlmax};
     long long c_acc = 0, c_rej = 0, c_bnd = 0, c_fm = 0;
 #ifdef MHD_PROFILE
     const long long k_t0 = clock64(), k_w0 = wall_clock64();
@@ -333,10 +358,10 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
 
         int st = propose_wave(frame, mn, kk, cz, test, tmp, lane);
         if (st == MHD_ST_OK && !sample_prior) {
-            build_layer_table(T, test, nl, p.vpvs, lane);
+            build_layer_table(T, test, nl, p.vpvs, lane, nlmax);
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred,
-                                       scratch, cnt, policy.stepwise(), pred,
+                                       scratch, cnt, policy.stepwise(), pred, pred,
                                        p.itype != MHD_PHASE ? 0 : (fabs(cz) <= hlim[kk] ? 2 : 1));
                 if (lane == 0)
                     hint_limit_update(hlim, kk, cz, __builtin_amdgcn_readfirstlane(g_PS.hinted));
@@ -359,11 +384,11 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
             if (acc) {
                 if (lane < NP) {
                     ch.params_prev[(size_t)ib * NP + lane] = mn[lane];
-                    m[lane] = test[lane];
+                    if (frame.used(lane)) m[lane] = test[lane];
                 }
                 logL = lnew;
                 if (!sample_prior)
-                    for (int k = lane; k < P; k += 64) pred[k] = newpred[k];
+                    for (int k = lane; k < ND; k += 64) pred[k] = newpred[k];
             }
         }
         __syncthreads();
@@ -387,7 +412,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
             if (hist_m && lane < NP) hist_m[(h * B + ib) * NP + lane] = m[lane];
             if (hist_logL && lane == 0) hist_logL[h * B + ib] = logL;
             if (hist_pred)
-                for (int k = lane; k < P; k += 64) hist_pred[(h * B + ib) * P + k] = pred[k];
+                for (int k = lane; k < ND; k += 64) hist_pred[(h * B + ib) * ND + k] = pred[k];
         }
     }
 
@@ -399,7 +424,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     }
 #endif
     if (lane < NP) ch.m[(size_t)ib * NP + lane] = m[lane];
-    for (int k = lane; k < P; k += 64) ch.pred[(size_t)ib * P + k] = pred[k];
+    for (int k = lane; k < ND; k += 64) ch.pred[(size_t)ib * ND + k] = pred[k];
     if (lane == 0) {
         ch.logL[ib] = logL;
         int64_t* c5 = ch.counters + (size_t)ib * 5;
@@ -645,7 +670,9 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     __shared__ double r_logL[NW];
     __shared__ unsigned long long r_lit[NW];
 
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (wave-uniform values are moved to scalar registers explicitly: what the compiler cannot
+    // prove uniform it keeps per lane, and those registers are spilled around every forward)
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     // the chain of this wave: the workgroup's own index, or its place in the launch schedule
     int ib = blockIdx.x;
     bool split = false;
@@ -662,7 +689,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             split = ib < nsplit;
             ib = split ? B - 2 * nsplit + 2 * ib + w : n4 + ib - nsplit;
         }
-        ib = sv.order[ib];
+        ib = __builtin_amdgcn_readfirstlane(sv.order[ib]);
         // nothing left of this call for the chain (a later phase): the workgroup is done
         if (!split && sv.progress[ib] >= S) return;
     }
@@ -681,7 +708,8 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     double* ghint = ghint_[g];
 
     const long long t_begin = wall_clock64();
-    const int nl = p.n_layers, NP = 2 * nl + 1, P = p.n_periods;
+    const int nlmax = p.n_layers, NP = 2 * nlmax + 1, P = p.n_periods, ND = data_length(p);
+    const int nl = layers_of(p, ib);
     LayerTable& T = g_T;
     if (lane == 0) g_PS.prof_slot = ib;
 
@@ -699,13 +727,13 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             mn[lane] = (m[lane] - lo[lane]) / rg[lane];
             hlim[lane] = (float)HINT_SECANT_CAUCHY;
         }
-        for (int k = lane; k < P; k += 64) pred[k] = ch.pred[(size_t)ib * P + k];
+        for (int k = lane; k < ND; k += 64) pred[k] = ch.pred[(size_t)ib * ND + k];
     }
-    double logL = ch.logL[ib];
-    const double beta = ch.beta ? ch.beta[ib] : 1.0;
+    double logL = uniform_value(ch.logL[ib]);
+    const double beta = uniform_value(ch.beta ? ch.beta[ib] : 1.0);
     const double* R = (rotate & MHD_ROT_FRAME) ? ch.rot + (size_t)ib * NP * NP : nullptr;
-    const ProposalFrame frame = {lo, hi, rg, wid, R, nl, NP};
-    long long c_acc = 0, c_rej = 0, c_bnd = 0, c_fm = 0;
+    const ProposalFrame frame = {lo, hi, rg, wid, R, nl, NP, nlmax};
+    int c_acc = 0, c_rej = 0, c_bnd = 0, c_fm = 0;
     unsigned long long lit = 0, exec = 0;
     // how the curves of this chain are searched (see SearchPolicy); a chain goes on at the
     // level its last launch ended with
@@ -734,12 +762,12 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     // chain's first wave computes them once per launch (and on every acceptance they are the
     // candidate's).
     if (writer && lane == 0) ghint_ok_[g] = 0;
-    if (p.itype == MHD_GROUP && p.mode == 0 && search == 2 && writer) {
+    if (p.itype != MHD_PHASE && p.mode == 0 && search == 2 && writer) {
         wave_sync();
-        build_layer_table(T, m, nl, p.vpvs, lane);
+        build_layer_table(T, m, nl, p.vpvs, lane, nlmax);
         EvalCount extra = {0, 0};
-        const int st0 = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
-                                          scratch[w], extra, 0, t, 0);
+        const int st0 = forward_predicted(T, p.wave, p.mode, MHD_GROUP, t, P, p.dc, p.dt, newpred[w],
+                                          scratch[w], extra, 0, t, t, 0);
         wave_sync();
         if (st0 == MHD_ST_OK)
             for (int k = lane; k < 2 * P; k += 64) ghint[k] = scratch[w][k];
@@ -750,9 +778,11 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     group_sync();
     const bool hinted = p.mode == 0 && (p.itype == MHD_PHASE || ghint_ok_[g] != 0);
     if (search == 2 && hinted) {
-        policy.max_level = 0;
-        policy.level = 0;
-        policy.left = 0;
+        policy.max_level = HINTED_MAX_LEVEL;
+        if (policy.level > policy.max_level) {
+            policy.level = policy.max_level;
+            policy.left = policy.level > 0 ? 8 : 0;
+        }
     }
 
     // everything one step leaves behind besides the state itself (the chain's first wave writes)
@@ -779,7 +809,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             if (hist_m && lane < NP) hist_m[(h * B + ib) * NP + lane] = m[lane];
             if (hist_logL && lane == 0) hist_logL[h * B + ib] = logL;
             if (hist_pred)
-                for (int k = lane; k < P; k += 64) hist_pred[(h * B + ib) * P + k] = pred[k];
+                for (int k = lane; k < ND; k += 64) hist_pred[(h * B + ib) * ND + k] = pred[k];
         }
     };
     // the start of step j: update_covariance_matrix sees the state the step starts from
@@ -796,20 +826,20 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             double dl = lnew - logL;
             dl = dl / Temp;
             if (ch.beta) dl = beta * dl;
-            acc = u_acc[(size_t)j * B + ib] <= exp(dl);
+            acc = __builtin_amdgcn_readfirstlane((int)(u_acc[(size_t)j * B + ib] <= exp(dl)));
             if (acc) {
                 if (writer) {
                     if (lane < NP) {
                         ch.params_prev[(size_t)ib * NP + lane] = mn[lane];
-                        m[lane] = test[c][lane];
+                        if (frame.used(lane)) m[lane] = test[c][lane];
                         mn[lane] = (m[lane] - lo[lane]) / rg[lane];
                     }
-                    for (int k = lane; k < P; k += 64) pred[k] = newpred[c][k];
-                    if (p.itype == MHD_GROUP)
+                    for (int k = lane; k < ND; k += 64) pred[k] = newpred[c][k];
+                    if (p.itype != MHD_PHASE)
                         for (int k = lane; k < 2 * P; k += 64) ghint[k] = scratch[c][k];
                     wave_sync();
                 }
-                logL = lnew;
+                logL = uniform_value(lnew);
             }
         }
         book(j, st, acc);
@@ -855,11 +885,10 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         double lnew = 0.0;
         EvalCount cnt = {0, 0};
         if (jc < S) {
-            build_layer_table(T, test[w], nl, p.vpvs, lane);
+            build_layer_table(T, test[w], nl, p.vpvs, lane, nlmax);
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
-                                       scratch[w], cnt, policy.stepwise(),
-                                       p.itype == MHD_PHASE ? pred : ghint,
+                                       scratch[w], cnt, policy.stepwise(), pred, ghint,
                                        !hinted ? 0 : (fabs(czc) <= hlim[kkc] ? 2 : 1));
                 trouble = __builtin_amdgcn_readfirstlane(g_PS.trouble);
                 // (the waves of a chain update the limits unordered; they are heuristics)
@@ -896,7 +925,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         bool trouble2 = false;
         for (int c = w0; c < w0 + nw; ++c) {
             ran += (r_step[c] < S);
-            trouble2 |= r_trouble[c] >= 2;
+            trouble2 |= r_trouble[c] >= (hinted ? HINTED_TROUBLE_MIN : 2);
         }
         for (int c = w0; c < w0 + nw; ++c) {
             const int j = r_step[c];  // <= S, increasing with c
@@ -949,7 +978,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     }
     if (writer) {
         if (lane < NP) ch.m[(size_t)ib * NP + lane] = m[lane];
-        for (int k = lane; k < P; k += 64) ch.pred[(size_t)ib * P + k] = pred[k];
+        for (int k = lane; k < ND; k += 64) ch.pred[(size_t)ib * ND + k] = pred[k];
     }
     if (lane == 0) {
         if (writer) {
@@ -1159,8 +1188,10 @@ int mhd_loglik_batch(const mhd_problem_t* prob, const double* pred, int32_t B, d
     return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_loglik_batch launch");
 }
 
-static int check_chains(const mhd_chains_t* ch, int rotate)
+static int check_chains(const mhd_chains_t* ch, int rotate, const mhd_problem_t* prob = nullptr)
 {
+    if (prob && prob->n_layers_b && rotate)
+        return fail(MHD_EINVAL, "rotated proposals are not available with n_layers_b");
     if (!ch) return fail(MHD_EINVAL, "chains is NULL");
     if (!ch->m || !ch->logL || !ch->pred || !ch->params_prev || !ch->width || !ch->counters)
         return fail(MHD_EINVAL, "chain state pointer is NULL");
@@ -1233,7 +1264,7 @@ static int mh_steps_check(const mhd_problem_t* prob, const mhd_chains_t* chains,
                           const double* u_acc, double T, int32_t rotate, int32_t hist_every)
 {
     if (int rc = check_problem(prob, true)) return rc;
-    if (int rc = check_chains(chains, rotate)) return rc;
+    if (int rc = check_chains(chains, rotate, prob)) return rc;
     if (B < 0 || n_steps < 0 || hist_every < 0) return fail(MHD_EINVAL, "negative size");
     if (!(T > 0.0)) return fail(MHD_EINVAL, "T must be positive");
     if (B == 0 || n_steps == 0) return 1;  // (no steps may come with NULL draw arrays)
@@ -1307,7 +1338,7 @@ int mhd_cov_accumulate(const mhd_problem_t* prob, const mhd_chains_t* chains, in
                        void* stream)
 {
     if (int rc = check_problem(prob, true)) return rc;
-    if (int rc = check_chains(chains, MHD_ROT_ACCUMULATE)) return rc;
+    if (int rc = check_chains(chains, MHD_ROT_ACCUMULATE, prob)) return rc;
     if (B < 0) return fail(MHD_EINVAL, "negative batch");
     if (B == 0) return MHD_OK;
     hipLaunchKernelGGL(cov_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *prob, *chains, B);

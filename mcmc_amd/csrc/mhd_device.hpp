@@ -482,15 +482,17 @@ __device__ inline double halfspace_rayleigh(double a, double b)
 // Build the LDS layer table from a parameter vector
 // [n_layers interface depths, n_layers+1 vs]  (model_params.py:187-198).
 // Called by every lane of the block; lanes < L fill one row each.
+// vs_at: the slot of the first layer's vs (n_layers, or the padded maximum when the batch
+// holds models of different layer counts).
 __device__ inline void build_layer_table(LayerTable& T, const double* m, int n_layers, double vpvs,
-                                         int lane)
+                                         int lane, int vs_at)
 {
     const int L = n_layers + 1;
     if (lane < L) {
         double dep = (lane < n_layers) ? m[lane] : 0.0;
         double prev = (lane > 0 && lane < n_layers) ? m[lane - 1] : 0.0;
         double d = (lane < n_layers) ? dep - prev : 0.0;
-        double vs = m[n_layers + lane];
+        double vs = m[vs_at + lane];
         double vp = vs * vpvs;
         double rho = (1741.0 * (double)sgni(vp) * pow(fabs(vp), 0.25)) / 1000.0;
         T.d[lane] = d;
@@ -793,13 +795,19 @@ __device__ MHD_NOINLINE int phase_curve_wave(const LayerTable& T, int wave, cons
     return MHD_ST_OK;
 }
 
-// forward_model for the table in T: phase or group velocity into vel[] (LDS).
+// forward_model for the table in T: phase or group velocity into vel[] (LDS), or both
+// (MHD_PHASE_AND_GROUP: phase in vel[0..P), group in vel[P..2P)).
 // scratch must hold 2*P doubles (LDS).  Wave-uniform.
 __device__ inline int forward_wave(const LayerTable& T, int wave, int mode, int itype,
                                    const double* t, int P, double dc, double dt, double* vel,
                                    double* scratch, EvalCount& cnt)
 {
     if (itype == MHD_PHASE) return phase_curve_wave(T, wave, t, P, 1.0, mode, dc, vel, cnt);
+    if (itype == MHD_PHASE_AND_GROUP) {
+        const int st0 = phase_curve_wave(T, wave, t, P, 1.0, mode, dc, vel, cnt);
+        if (st0 != MHD_ST_OK) return st0;
+        vel += P;
+    }
     double* c1 = scratch;
     double* c2 = scratch + P;
     int st = phase_curve_wave(T, wave, t, P, 1.0 + dt, mode, dc, c1, cnt);
@@ -843,11 +851,17 @@ __device__ inline double npsum_small(const double* a, int n)
     return res;
 }
 
-// Model.get_likelihood for one predicted curve in LDS; term[] is LDS scratch [P].
+// Entries of the data vectors (obs, pred, noise) of a problem.
+__device__ __host__ inline int data_length(const mhd_problem_t& p)
+{
+    return p.itype == MHD_PHASE_AND_GROUP ? 2 * p.n_periods : p.n_periods;
+}
+
+// Model.get_likelihood for one predicted curve in LDS; term[] is LDS scratch [ND].
 __device__ inline double loglik_wave(const mhd_problem_t& p, const double* pred, double* term,
                                      int lane)
 {
-    const int P = p.n_periods;
+    const int P = data_length(p);
     for (int k = lane; k < P; k += 64) {
         const double r = p.obs[k] - pred[k];
         if (p.noise_dist == MHD_NORMAL) {

@@ -1110,6 +1110,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
 #endif
             S.trouble = repairs + 1;
             CHAIN_EVENT(4)
+            if (S.hinted == 1) CHAIN_EVENT(27)
             if (++repairs > MAX_REPAIRS) {
                 CHAIN_EVENT(10)
                 const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kbad, s1st);
@@ -1237,13 +1238,16 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
 }
 
 // forward_model with the period-parallel curve where it applies (fundamental mode).
+// hint: the phase curve of a similar model (MHD_PHASE, MHD_PHASE_AND_GROUP); hint2: its two
+// phase curves at t/(1+dt) and t/(1-dt), P values each (MHD_GROUP, MHD_PHASE_AND_GROUP).
 __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode, int itype,
                                         const double* t, int P, double dc, double dt,
                                         double* vel, double* scratch, EvalCount& cnt,
-                                        int stepwise, const double* hint, int use_hint)
+                                        int stepwise, const double* hint, const double* hint2,
+                                        int use_hint)
 {
-    // (hint is never tested against null: a null test of a pointer into LDS trips the compiler;
-    // without a hint the callers pass any valid pointer and use_hint = false)
+    // (the hints are never tested against null: a null test of a pointer into LDS trips the
+    // compiler; without a hint the callers pass any valid pointer and use_hint = 0)
     if (mode != 0) {
         // the callers read these after every forward: higher modes use no predictor
         if ((threadIdx.x & 63) == 0) {
@@ -1253,7 +1257,8 @@ __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode,
         wave_sync();
         return forward_wave(T, wave, mode, itype, t, P, dc, dt, vel, scratch, cnt);
     }
-    if (itype == MHD_PHASE) {
+    int trouble = 0;
+    if (itype != MHD_GROUP) {
         const int st = phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt, stepwise, hint, use_hint);
 #ifdef MHD_PROFILE
         if (use_hint && st == MHD_ST_OK) {
@@ -1265,17 +1270,22 @@ __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode,
             if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[21 + bkt], 1ull);
         }
 #endif
-        return st;
+        if (itype == MHD_PHASE || st != MHD_ST_OK) return st;
+        trouble = __builtin_amdgcn_readfirstlane(g_PS.trouble);
+        vel += P;
     }
     double* c1 = scratch;
     double* c2 = scratch + P;
-    // (group velocity: the hint holds the two phase curves of the similar model, P values each)
-    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt, stepwise, use_hint ? hint : t,
-                                   use_hint);
+    int st = phase_curve_predicted(wave, t, P, 1.0 + dt, dc, c1, cnt, stepwise,
+                                   use_hint ? hint2 : t, use_hint);
     if (st != MHD_ST_OK) return st;
-    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt, stepwise, use_hint ? hint + P : t,
-                               use_hint);
+    trouble += __builtin_amdgcn_readfirstlane(g_PS.trouble);
+    st = phase_curve_predicted(wave, t, P, 1.0 - dt, dc, c2, cnt, stepwise,
+                               use_hint ? hint2 + P : t, use_hint);
     if (st != MHD_ST_OK) return st;
+    // (the repairs of all the curves of this forward)
+    if ((threadIdx.x & 63) == 0) g_PS.trouble += trouble;
+    wave_sync();
     for (int k = 0; k < P; ++k) {
         if (c1[k] > 0.0 && c2[k] > 0.0) {
             const double t1 = t[k] / (1.0 + dt), t2 = t[k] / (1.0 - dt);

@@ -66,13 +66,16 @@ class DeviceProblem:
         self.n_layers = int(n_layers)
         self.NP = 2 * self.n_layers + 1
         self.search, self.candidates = int(search), int(candidates)
+        itype_code = {"phase": L.PHASE, "group": L.GROUP, "phase+group": L.PHASE_AND_GROUP}[itype]
         with torch.cuda.device(self.device):
             L.check(L.lib().mhd_init(self.device.index))
         periods = np.ascontiguousarray(periods, dtype=np.float64)
         self.P = len(periods)
+        # entries of the data vectors: the phase curve, the group curve, or both in a row
+        self.ND = 2 * self.P if itype == "phase+group" else self.P
         if self.n_layers < 1 or self.n_layers > L.MAX_LAYERS:
             raise ValueError("n_layers outside the compiled limit")
-        if self.P < 1 or self.P > L.MAX_PERIODS:
+        if self.P < 1 or self.ND > L.MAX_PERIODS:
             raise ValueError("number of periods outside the compiled limit")
         f64 = dict(dtype=torch.float64, device=self.device)
         self.periods = torch.tensor(periods, **f64)
@@ -91,7 +94,7 @@ class DeviceProblem:
         self.c = L.Problem(
             n_layers=self.n_layers, n_periods=self.P,
             wave={"rayleigh": L.RAYLEIGH, "love": L.LOVE}[wave], mode=int(mode),
-            itype={"phase": L.PHASE, "group": L.GROUP}[itype], noise_dist=code, n_noise_a=n_a,
+            itype=itype_code, noise_dist=code, n_noise_a=n_a,
             n_noise_b=n_b, vpvs=float(vpvs), dc=float(dc), dt=float(dt),
             periods=self.periods.data_ptr(),
             obs=None if self.obs is None else self.obs.data_ptr(),
@@ -99,22 +102,35 @@ class DeviceProblem:
             noise_b=None if self.noise_b is None else self.noise_b.data_ptr(),
             bounds=None if self.bounds is None else self.bounds.data_ptr())
 
-    def cref(self):
-        """The struct for a call, with the tuning switches as they stand now."""
+    def cref(self, n_layers_b=None):
+        """The struct for a call, with the tuning switches as they stand now and the layer
+        counts of the batch of this call (int32 device tensor [B], or None: all n_layers)."""
+        self.c.n_layers_b = None if n_layers_b is None else n_layers_b.data_ptr()
         self.c.search = self.search or _TUNING["search"]
         self.c.candidates = self.candidates or _TUNING["candidates"]
         return ctypes.byref(self.c)
 
     # -- forward_model for a batch (src/inversion/model_params.py:178-209) --
-    def forward(self, params, n_evals=None):
-        """params [B,NP] device tensor -> (vel [B,P], status [B] int32)."""
+    def layer_counts(self, n_layers_b, B):
+        """int32 device tensor [B] of per-model layer counts, checked; None passes through."""
+        if n_layers_b is None:
+            return None
+        nb = torch.as_tensor(np.asarray(n_layers_b.cpu() if torch.is_tensor(n_layers_b)
+                                        else n_layers_b), dtype=torch.int32)
+        assert nb.shape == (B,) and int(nb.min()) >= 1 and int(nb.max()) <= self.n_layers
+        return nb.to(self.device).contiguous()
+
+    def forward(self, params, n_evals=None, n_layers_b=None):
+        """params [B,NP] device tensor -> (vel [B,ND], status [B] int32).  n_layers_b: layer
+        count of every model of the batch (padded rows, see mhd_problem_t.n_layers_b)."""
         params = params.contiguous()
         B = params.shape[0]
         assert params.shape[1] == self.NP and params.dtype == torch.float64
-        vel = torch.empty((B, self.P), dtype=torch.float64, device=self.device)
+        vel = torch.empty((B, self.ND), dtype=torch.float64, device=self.device)
         status = torch.empty(B, dtype=torch.int32, device=self.device)
+        nb = self.layer_counts(n_layers_b, B)
         with torch.cuda.device(self.device):
-            L.check(L.lib().mhd_forward_batch(self.cref(), _ptr(params), B, _ptr(vel),
+            L.check(L.lib().mhd_forward_batch(self.cref(nb), _ptr(params), B, _ptr(vel),
                                               _ptr(status), _ptr(n_evals), _stream(self.device)))
         return vel, status
 
@@ -142,15 +158,16 @@ class DeviceProblem:
 class DeviceChains:
     """State of B chains on the device (struct mhd_chains)."""
 
-    def __init__(self, prob, m, width, beta=None, individual_acceptance=False):
+    def __init__(self, prob, m, width, beta=None, individual_acceptance=False, n_layers_b=None):
         self.prob = prob
         dev = prob.device
         f64 = dict(dtype=torch.float64, device=dev)
         self.m = torch.as_tensor(np.asarray(m, dtype=np.float64), **f64).contiguous() \
             if not torch.is_tensor(m) else m.to(**f64).contiguous()
         self.B = B = self.m.shape[0]
-        NP, P = prob.NP, prob.P
+        NP, P = prob.NP, prob.ND
         assert self.m.shape[1] == NP
+        self.n_layers_b = prob.layer_counts(n_layers_b, B)
         w = np.broadcast_to(np.asarray(width, dtype=np.float64), (B, NP))
         self.width = torch.tensor(np.ascontiguousarray(w), **f64)
         self.logL = torch.zeros(B, **f64)
@@ -186,7 +203,7 @@ class DeviceChains:
 
     def init_likelihood(self):
         """pred, logL of the current parameters; returns status [B]."""
-        vel, status = self.prob.forward(self.m)
+        vel, status = self.prob.forward(self.m, n_layers_b=self.n_layers_b)
         self.pred.copy_(vel)
         self.logL.copy_(self.prob.loglik(vel))
         return status
@@ -219,14 +236,14 @@ class DeviceChains:
             hl = torch.empty((S // hist_every, B), dtype=torch.float64, device=dev)
             out["hist_m"], out["hist_logL"] = hm, hl
             if want_pred_hist:
-                hp = torch.empty((S // hist_every, B, self.prob.P), dtype=torch.float64,
+                hp = torch.empty((S // hist_every, B, self.prob.ND), dtype=torch.float64,
                                  device=dev)
                 out["hist_pred"] = hp
         ch = self.struct()
         with torch.cuda.device(dev):
             entry = L.lib().mhd_mh_steps_static if static_scratch else L.lib().mhd_mh_steps
             L.check(entry(
-                self.prob.cref(), ctypes.byref(ch), B, S, _ptr(idx), _ptr(cauchy),
+                self.prob.cref(self.n_layers_b), ctypes.byref(ch), B, S, _ptr(idx), _ptr(cauchy),
                 _ptr(u_acc), float(T), int(rotate), int(bool(sample_prior)), _ptr(acc),
                 _ptr(st), int(hist_every), _ptr(hm), _ptr(hl), _ptr(hp), _ptr(self.n_evals),
                 _stream(dev)))

@@ -24,6 +24,11 @@ Differences from the reference, all deliberate:
     n_temps rungs each, n_temps * n_chains replicas in all, exchanges inside each
     ladder.  Without it the reference's meaning holds: n_chains > 1 is ONE ladder
     with n_chains rungs.
+  * layer_counts (not in the reference, whose README names a trans-dimensional
+    parameterisation without code for it): chains of one run may have different
+    numbers of layers, up to model_params.n_layers; every chain keeps its count,
+    there are no birth / death moves.  Rows are padded (see mhd_problem_t.n_layers_b)
+    and the perturbed parameter is drawn among the chain's own.
   * Results go to chunked .npz files (input-<name>.npz once, results-<name>-
     <chunk>.npz every n_chunk steps) with the reference's variable names
     (src/inversion/inversion.py:150-231) instead of a netCDF file that is re-read
@@ -74,7 +79,7 @@ class Inversion:
                  n_cov_chunk=200, n_thin=1, n_chains=1, individual_acceptance=False,
                  beta_spacing_factor=None, out_filename=None, set_starting_model=False,
                  out_dir="./results/inversion/", reference_betas=False, swap_seed=0,
-                 n_temps=None, layout="ladder"):
+                 n_temps=None, layout="ladder", layer_counts=None):
         import torch.distributed as dist
         self.data = data
         self.n_burn, self.n_chunk, self.n_mcmc, self.n_thin = n_burn, n_chunk, n_mcmc, n_thin
@@ -99,6 +104,13 @@ class Inversion:
         self.n_local = self.n_replicas // self.world
         self._lo = self.rank * self.n_local
         self.swap_rng = np.random.RandomState(swap_seed)  # identical on every rank
+        # finite layers of every replica (None: all have model_params.n_layers)
+        self.layer_counts = None
+        if layer_counts is not None:
+            lc = np.asarray(layer_counts, dtype=np.int32)
+            if lc.shape != (self.n_replicas,) or lc.min() < 1 or lc.max() > model_params.n_layers:
+                raise ValueError("layer_counts: one count in 1..n_layers per replica")
+            self.layer_counts = lc[self._lo:self._lo + self.n_local].copy()
         self.out_dir = out_dir
         # results are written only when the caller names a file (the reference makes up a name
         # from the clock, src/inversion/inversion.py:62-66; with several ranks those would differ)
@@ -140,13 +152,15 @@ class Inversion:
         NP = model_params.n_model_params
         n = self.n_local
         starts = np.empty((n, NP))
+        lc = self.layer_counts
         if set_starting_model:
             starts[:] = np.asarray(self.data.model_true, dtype=float)[None, :]
         else:
             todo = np.arange(n)
             while todo.size:
                 cand = np.random.uniform(pb[:, 0], pb[:, 1], size=(todo.size, NP))
-                _, status = model_params.forward_model_batch(self.data.periods, cand)
+                _, status = model_params.forward_model_batch(
+                    self.data.periods, cand, None if lc is None else lc[todo])
                 ok = status == L.ST_OK
                 starts[todo[ok]] = cand[ok]
                 todo = todo[~ok]
@@ -161,7 +175,7 @@ class Inversion:
         self.swap_counts = torch.zeros(2, dtype=torch.int64, device=dev)
         self.state = DeviceChains(self.prob, starts, model_params.assemble_proposal_width(),
                                   beta=self.beta_all[self._lo:self._lo + n],
-                                  individual_acceptance=individual_acceptance)
+                                  individual_acceptance=individual_acceptance, n_layers_b=lc)
         status = self.state.init_likelihood()
         if int((status != 0).sum()):
             raise DispersionError("starting model has no dispersion curve")
@@ -248,7 +262,13 @@ class Inversion:
 
     def _draws(self, S):
         NP = self.model_params.n_model_params
-        idx = np.random.randint(NP, size=(S, self.n_local)).astype(np.int32)
+        if self.layer_counts is None:
+            idx = np.random.randint(NP, size=(S, self.n_local)).astype(np.int32)
+        else:
+            # one of the chain's own 2 n + 1 parameters, as the slot of its padded row
+            n, nmax = self.layer_counts[None, :], self.model_params.n_layers
+            j = np.random.randint(2 * n + 1, size=(S, self.n_local))
+            idx = np.where(j < n, j, nmax + j - n).astype(np.int32)
         cz = np.tan(np.pi * (np.random.uniform(size=(S, self.n_local)) - 0.5))
         xi = np.random.uniform(size=(S, self.n_local))
         return idx, cz, xi

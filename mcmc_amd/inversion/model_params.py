@@ -21,7 +21,8 @@ class DispersionCurveParams(ModelParams):
     Parameters are [n_layers interface depths (km), n_layers+1 shear velocities (km/s)];
     vp = vs * vpvs_ratio and density follows Gardner's relation.  forward_model runs the HIP
     kernel; wave / mode / itype select what disba's PhaseDispersion / GroupDispersion would be
-    asked for (the reference always uses Rayleigh, mode 0, phase velocity).
+    asked for (the reference always uses Rayleigh, mode 0, phase velocity); itype
+    "phase+group" predicts both curves as one datum of twice the length.
     """
 
     def __init__(self, n_layers, param_bounds, proposal_width, vpvs_ratio, wave="rayleigh",
@@ -105,12 +106,13 @@ class DispersionCurveParams(ModelParams):
                              noise_params, self.assemble_param_bounds(), wave=self.wave,
                              mode=self.mode, itype=self.itype, dc=self.dc, dt=self.dt)
 
-    def forward_model_batch(self, periods, model_params):
-        """[B, n_model_params] -> (velocity [B, n_periods], status [B]) as numpy arrays."""
+    def forward_model_batch(self, periods, model_params, layer_counts=None):
+        """[B, n_model_params] -> (velocity [B, n_data], status [B]) as numpy arrays.
+        layer_counts: finite layers of every model when they differ (padded rows)."""
         import torch
         prob = self.device_problem(periods)
         m = torch.tensor(np.ascontiguousarray(model_params, dtype=np.float64), device=prob.device)
-        vel, status = prob.forward(m)
+        vel, status = prob.forward(m, n_layers_b=layer_counts)
         return vel.cpu().numpy(), status.cpu().numpy()
 
     def forward_model(self, periods, model_params):

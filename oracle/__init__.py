@@ -89,7 +89,7 @@ def secular(d, a, b, rho, period, c, wave=0):
 
 def dispersion(d, a, b, rho, periods, wave=0, mode=0, itype=0, dc=0.005, dt=0.025):
     d, a, b, rho, periods = map(_f64, (d, a, b, rho, periods))
-    vel = np.zeros(len(periods))
+    vel = np.zeros(len(periods) * (2 if itype == 2 else 1))
     ne = ctypes.c_longlong(0)
     st = lib().orc_dispersion(_d(d), _d(a), _d(b), _d(rho), len(d), _d(periods), len(periods),
                               wave, mode, itype, dc, dt, _d(vel), ctypes.byref(ne))
@@ -97,9 +97,10 @@ def dispersion(d, a, b, rho, periods, wave=0, mode=0, itype=0, dc=0.005, dt=0.02
 
 
 def forward(m, n_layers, vpvs, periods, wave=0, mode=0, itype=0, dc=0.005, dt=0.025):
-    """forward_model(periods, model_params): returns (status, velocity[P], n_evals)."""
+    """forward_model(periods, model_params): returns (status, velocity[P], n_evals); itype 2:
+    velocity[2P] = the phase curve, then the group curve."""
     m, periods = _f64(m), _f64(periods)
-    vel = np.zeros(len(periods))
+    vel = np.zeros(len(periods) * (2 if itype == 2 else 1))
     ne = ctypes.c_longlong(0)
     st = lib().orc_forward(_d(m), n_layers, vpvs, _d(periods), len(periods), wave, mode, itype,
                            dc, dt, _d(vel), ctypes.byref(ne))
@@ -110,7 +111,7 @@ def forward_batch(params, n_layers, vpvs, periods, wave=0, mode=0, itype=0, dc=0
                   nthreads=1):
     params, periods = _f64(params), _f64(periods)
     B, P = params.shape[0], len(periods)
-    vel = np.zeros((B, P))
+    vel = np.zeros((B, 2 * P if itype == 2 else P))
     status = np.zeros(B, dtype=np.int32)
     ne = ctypes.c_longlong(0)
     lib().orc_forward_batch(_d(params), B, n_layers, vpvs, _d(periods), P, wave, mode, itype, dc,
@@ -177,7 +178,8 @@ def mh_step(state, idx, cauchy, u_acc, n_layers, vpvs, periods, obs, noise_dist,
             sample_prior=False):
     periods, obs = _f64(periods), _f64(obs)
     P = len(periods)
-    code, na, nb = noise_arrays(noise_dist, noise_params, P)
+    assert len(obs) == (2 * P if itype == 2 else P)
+    code, na, nb = noise_arrays(noise_dist, noise_params, len(obs))
     idx = np.ascontiguousarray(idx, dtype=np.int32)
     cauchy, u_acc = _f64(cauchy), _f64(u_acc)
     beta = None if beta is None else _f64(beta)

@@ -37,3 +37,7 @@ for label,idxs in (("median 3",order[510:513]),("slowest 8",order[-8:])):
     print(label)
     for i in idxs:
         print("  chain %4d dur %5.0f us rounds %2d fw %2d | Mcyc predict %.2f refine %.2f replay %.2f verify %.2f repair %.2f giveup %.2f | "%(i,dur[i],rounds[i],fw[i],*(b[i,j]/1e6 for j in range(6)))+" ".join("%s %d"%(n,ev[i,k]) for k,n in names.items()))
+tot=ev.sum(axis=0)
+print("all chains: forwards %d hint tried %d gave up %d | repairs %d (after a settled hint %d) | sequential answer above/below/at the predicted root %d/%d/%d | first wrong sign in scan %d in halvings %d | resynced %d repredicted %d seqfinish %d notplain %d"%(tot[0],tot[1],tot[2],tot[4],tot[27],tot[16],tot[17],tot[18],tot[19],tot[20],tot[26],tot[5],tot[10],tot[7]))
+rep=ev[:,4]/np.maximum(ev[:,0],1)
+print("repairs per forward over chains: p50 %.2f p90 %.2f p99 %.2f max %.2f; corr with duration %.2f"%(*np.percentile(rep,[50,90,99,100]),np.corrcoef(rep,dur)[0,1]))

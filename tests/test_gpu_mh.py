@@ -23,7 +23,7 @@ def _noise(g):
 
 
 @pytest.mark.parametrize("case", ["3layer_normal", "6layer_normal", "6layer_asymlaplace",
-                                  "3layer_individual_T2"])
+                                  "3layer_individual_T2", "asymlaplace_WH01"])
 def test_reference_trace(case):
     import torch
     from mcmc_amd.engine import DeviceChains, DeviceProblem

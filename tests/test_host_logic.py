@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib.mhd_abi_version.restype = ctypes.c_int
     assert lib.mhd_abi_version() == L.ABI_VERSION
     # struct layouts agree with the header's field order and sizes
-    assert ctypes.sizeof(L.Problem) == 8 * 4 + 3 * 8 + 5 * 8 + 2 * 4
+    assert ctypes.sizeof(L.Problem) == 8 * 4 + 3 * 8 + 6 * 8 + 2 * 4
     assert ctypes.sizeof(L.Chains) == 12 * 8
 
 

@@ -283,6 +283,20 @@ def main():
     run_case("3layer_rotate", 3, b3, p20, [0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0],
              "normal", {"std": 0.025}, n_steps=60, seed=5, rotate=True, n_burn=10, n_cov_chunk=5,
              n_thin=2)
+    # the reference's one working configuration (src/main.py:380-407 -> :261-347): two layers,
+    # asymmetric-Laplace likelihood, the 60 periods and per-period lambda scaling of site WH01
+    # (flipped, clipped at 60: src/main.py:313-317), lambd = 1, kappa = 0.75, bounds of
+    # src/main.py:61-64, started at the true model (src/main.py:152-153)
+    import pandas as pd
+    df = pd.read_csv("/root/reference/data/spread/WH01-asym-laplace-params.csv")
+    lam_scale = np.flip(df["scaled_lambd"].values).copy()
+    lam_scale[lam_scale > 60] = 60
+    b2 = {"depth": np.array([0.001, 0.10]),
+          "vel_s": np.array([[0.100, 0.700], [0.100, 0.700], [1.000, 2.000]])}
+    wh01_true = [0.010, 0.063, 0.200, 0.400, 1.700]
+    run_case("asymlaplace_WH01", 2, b2, np.flip(1 / df["freqs"].values).copy(), wh01_true,
+             "asym-laplace", {"lambd_scale": lam_scale, "lambd": 1.0, "kappa": 0.75},
+             n_steps=400, seed=6, start=wh01_true)
     misc_fixture()
 
 
