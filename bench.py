@@ -110,7 +110,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--chunk", type=int, default=250, help="MH steps per kernel launch")
+    ap.add_argument("--chunk", type=int, default=500,
+                    help="MH steps per call of mhd_mh_steps: the reference's cadence of host work "
+                         "(n_chunk = n_cov_chunk = 500, src/main.py:127-129)")
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--search", type=int, default=2,

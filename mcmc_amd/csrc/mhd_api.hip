@@ -740,9 +740,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     const bool keeps = ch.sched && B <= SCHED_MAX_CHAINS;
     SearchPolicy policy = {search == 2 ? 0 : 3, 0, p.itype == MHD_PHASE ? 0 : 3};
     if (search == 2 && keeps) {
-        // (NW = 4 serves the expensive chains, which mostly sit at level 1 or above; reading
-        // the level there trips an instruction-selection bug of the compiler, so it is fixed)
-        int lv = (NW == 4) ? 1 : ((int)sched_view(ch.sched, B).level[ib] & 3);
+        int lv = (int)sched_view(ch.sched, B).level[ib] & 3;
         if (lv > policy.max_level) lv = policy.max_level;
         policy.level = lv;
         policy.left = lv > 0 ? 8 : 0;

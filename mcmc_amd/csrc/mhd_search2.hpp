@@ -829,6 +829,62 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
     return __hiloint2double(hi, lo);
 }
 
+// Scan and halvings of one plain period.  BELOW: the start lies on the root's lower side (the scan
+// goes upward); otherwise on its upper side (it goes downward).  c1 is the end of the bracket on
+// the start's side throughout.  Written once per side so that a halving is an add, a multiply,
+// a compare and two selects, with no flag to combine.
+template <bool BELOW>
+__device__ __forceinline__ bool replay_search(double start, double lo, double hi, double dc,
+                                              double cc, double top, int& ns_out, int& nh_out,
+                                              double& c3_out)
+{
+    const double step = BELOW ? dc : -dc;
+    double c1 = start, c2 = start + step;
+    int ns = 2;
+    // the abscissae rise (fall) monotonically: the floor and the ceiling need to be looked at
+    // for the first and the last one only
+    if (BELOW ? uni(!(c2 > cc) || !(lo < top)) : uni(!(start < top))) return false;
+    while (uni(BELOW ? (c2 <= lo) : !(c2 <= lo))) {
+        if (ns >= MAX_SCAN) return false;
+        c1 = c2;
+        c2 = c2 + step;
+        ++ns;
+    }
+    if (!BELOW && !uni(c2 > cc)) return false;
+    const int e_apart = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fabs(c1 - c2)));
+    const int e_ends = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fmax(c1, c2)));
+    // |c1 - c2| >= 2^(e_apart - 1), the ends stay below 2^e_ends: after n halvings the ends are
+    // at least 2^(e_apart - 1 - n - e_ends) of the larger one apart
+    int sure = e_apart - 1 - e_ends + 19;
+    sure = sure < 0 ? 0 : (sure > 38 ? 38 : sure);
+    double c3 = 0.0;
+    int nh = 0;
+#pragma unroll 4
+    for (; nh < sure; ++nh) {
+        c3 = 0.5 * (c1 + c2);
+        const bool low = c3 <= lo;
+        // BELOW: a midpoint on the lower side replaces c1; otherwise it replaces c2
+        c1 = (low == BELOW) ? c3 : c1;
+        c2 = (low == BELOW) ? c2 : c3;
+    }
+    for (;;) {
+        if (nh >= 40) return false;
+        c3 = 0.5 * (c1 + c2);
+        const bool low = c3 <= lo;
+        ++nh;
+        c1 = (low == BELOW) ? c3 : c1;
+        c2 = (low == BELOW) ? c2 : c3;
+        if (uni(fabs(c1 - c2) <= 1.0e-6 * c1)) break;
+    }
+    // an abscissa inside the root's bracket [lo, hi] would have become an end of [c1, c2]
+    // (c1 is on lo's side by construction)
+    if (!uni(BELOW ? c2 >= hi : c1 >= hi)) return false;
+    ns_out = ns;
+    nh_out = nh;
+    c3_out = c3;
+    return true;
+}
+
 __device__ __forceinline__ ReplayPass replay_pass(int kstart, int nP, double* c, double cc,
                                                   double dc, double top, double betmx, int& s1st)
 {
@@ -843,7 +899,12 @@ __device__ __forceinline__ ReplayPass replay_pass(int kstart, int nP, double* c,
         const int kmine = kb + lane;
         const bool mine = kmine < nP;
         const double lo_v = mine ? S.lo[kmine] : 0.0, hi_v = mine ? S.hi[kmine] : 0.0;
-        const int sg_v = mine ? (((int)S.slo[kmine] & 0xff) | (((int)S.shi[kmine] & 0xff) << 8)) : 0;
+        // bit 0: the bracket's ends have opposite, non-zero signs; bit 1: the lower one is positive
+        int sg_v = 0;
+        if (mine) {
+            const int slo = S.slo[kmine], shi = S.shi[kmine];
+            sg_v = (int)(slo != 0 && shi != 0 && slo != shi) | ((int)(slo > 0) << 1);
+        }
         double r_start = 0.0, r_c = 0.0;
         int r_meta = 0, r_off = 0;
         const int kchunk = (nP - kb < 64) ? nP - kb : 64;
@@ -852,79 +913,19 @@ __device__ __forceinline__ ReplayPass replay_pass(int kstart, int nP, double* c,
             const int k = kb + kk;
             const double lo = readlane_f64(lo_v, kk), hi = readlane_f64(hi_v, kk);
             const int sg = __builtin_amdgcn_readlane(sg_v, kk);
-            const int slo = (int)(signed char)(sg & 0xff), shi = (int)(signed char)((sg >> 8) & 0xff);
+            const int slo = (sg & 2) ? 1 : -1;
             const bool ifirst = (k == 0);
             const double start = ifirst ? cc : cprev - 1.5 * dc;
-            double c1 = start, c2 = start;
-            const bool below1 = uni(c1 <= lo);
-            const int sfirst = below1 ? slo : shi;
+            const bool below1 = uni(start <= lo);
+            const int sfirst = below1 ? slo : -slo;
             const bool upward = ifirst || s1 * sfirst >= 0;
-            // the scan arrives at the root only when it moves towards it
-            bool plain = slo != 0 && shi != 0 && slo != shi && (upward == below1);
-            const double step = upward ? dc : -dc;
-            int ns = 1;
-            if (plain) {
-                for (;;) {
-                    c2 = c1 + step;
-                    ++ns;
-                    // (the floor is both clow and cm in the fundamental mode)
-                    if (uni((c2 <= lo) != below1)) {
-                        plain = uni(c2 > cc) && ns <= MAX_SCAN;
-                        break;
-                    }
-                    if (uni(!(c2 > cc) || c2 >= top) || ns >= MAX_SCAN) {
-                        plain = false;
-                        break;
-                    }
-                    c1 = c2;
-                }
-            }
-            int nh = 0;
+            int ns = 0, nh = 0;
             double c3 = 0.0;
-            if (plain) {
-                const int e_apart =
-                    __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fabs(c1 - c2)));
-                const int e_ends =
-                    __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(fmax(c1, c2)));
-                // |c1 - c2| >= 2^(e_apart - 1), the ends stay below 2^e_ends: after n halvings
-                // the ends are at least 2^(e_apart - 1 - n - e_ends) of the larger one apart
-                int sure = e_apart - 1 - e_ends + 19;
-                sure = sure < 0 ? 0 : (sure > 38 ? 38 : sure);
-                // (below1 fixes which end a midpoint on the root's lower side replaces: two copies
-                // of the loop, no flag to combine with the compare)
-                if (below1) {
-#pragma unroll 4
-                    for (; nh < sure; ++nh) {
-                        c3 = 0.5 * (c1 + c2);
-                        const bool low = c3 <= lo;
-                        c1 = low ? c3 : c1;
-                        c2 = low ? c2 : c3;
-                    }
-                } else {
-#pragma unroll 4
-                    for (; nh < sure; ++nh) {
-                        c3 = 0.5 * (c1 + c2);
-                        const bool low = c3 <= lo;
-                        c2 = low ? c3 : c2;
-                        c1 = low ? c1 : c3;
-                    }
-                }
-                bool converged = false;
-                while (nh < 40) {
-                    c3 = 0.5 * (c1 + c2);
-                    const bool left = (c3 <= lo) != below1;
-                    ++nh;
-                    c2 = left ? c3 : c2;
-                    c1 = left ? c1 : c3;
-                    if (__ballot(fabs(c1 - c2) <= 1.0e-6 * c1) != 0ull) {
-                        converged = true;
-                        break;
-                    }
-                }
-                plain = converged;
-                // an abscissa inside the bracket would have become an end of [c1, c2]
-                plain = plain && uni(fmin(c1, c2) <= lo && fmax(c1, c2) >= hi);
-            }
+            // the scan arrives at the root only when it moves towards it
+            bool plain = (sg & 1) && (upward == below1);
+            if (plain)
+                plain = below1 ? replay_search<true>(start, lo, hi, dc, cc, top, ns, nh, c3)
+                               : replay_search<false>(start, lo, hi, dc, cc, top, ns, nh, c3);
             if (!plain) {
                 o.kplain = k;
                 stop = true;
@@ -938,7 +939,7 @@ __device__ __forceinline__ ReplayPass replay_pass(int kstart, int nP, double* c,
             }
             o.npts += ns + nh;
             o.kend = k + 1;
-            if (ifirst) s1 = __builtin_amdgcn_readfirstlane(sfirst);
+            if (ifirst) s1 = sfirst;
             cprev = c3;
             if (!uni(c3 <= betmx)) {
                 o.kfail = k;
