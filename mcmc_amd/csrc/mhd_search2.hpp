@@ -107,6 +107,14 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
 
 #pragma clang fp contract(off)
 
+// The verification with two abscissae per lane (eval_secular2) or one.  Two per lane halve the
+// rounds but not the time: with two waves on a SIMD the FP64 pipe is saturated either way (an
+// isolated evaluation kernel gains 10 %, scratch/evalbench); measured on the benchmark: +3 %
+// on long calls, -2 % on 20-step calls.
+#ifndef VERIFY_PAIRS
+#define VERIFY_PAIRS 1
+#endif
+
 #ifdef MHD_PROFILE
 __device__ unsigned long long g_prof[64];
 __device__ unsigned long long g_times[4096];
@@ -995,6 +1003,96 @@ __device__ __forceinline__ void replay_abscissae(int k, int q, double dc, double
     xb = x;
 }
 
+// The period that abscissa i of a replay pass over periods kstart..kend-1 belongs to.
+__device__ __forceinline__ int period_of_abscissa(int i, int kstart, int kend)
+{
+    const PredictScratch& S = g_PS;
+    int a = kstart, b = kend - 1;
+    while (a < b) {
+        const int mid = (a + b + 1) >> 1;
+        if ((int)S.roff[mid] <= i) a = mid; else b = mid - 1;
+    }
+    return a;
+}
+
+// ---- stage 4 ----------------------------------------------------------------
+// Really evaluates abscissae vbeg..npts-1 of the replay pass over periods kstart..kend-1 and
+// returns the first whose sign is not the inferred one (or whose value is not the answer the
+// replay gave for its period), npts if there is none.  Out of line, with the pair evaluation
+// inlined: its registers are saved once per pass, not once per round.
+__device__ MHD_NOINLINE int verify_pass(int wave, const double* t, double tscale, double dc,
+                                        const double* c, int kstart, int kend, int kfail,
+                                        int vbeg, int npts, EvalCount& cnt)
+{
+    const PredictScratch& S = g_PS;
+    const int lane = threadIdx.x & 63;
+    auto period_of = [&](int i) -> int { return period_of_abscissa(i, kstart, kend); };
+    unsigned long long exec = 0;
+    int first_bad = npts;
+#if !VERIFY_PAIRS
+            for (int base = vbeg; base < npts; base += 64) {
+                const int i = base + lane;
+                const bool act = i < npts;
+                bool bad = false;
+                if (act) {
+                    const int k = period_of(i);
+                    const int q = i - (int)S.roff[k];
+                    double x, xnext;
+                    replay_abscissae(k, q, dc, x, xnext);
+                    const int want = (x <= S.lo[k]) ? (int)S.slo[k] : (int)S.shi[k];
+                    const double omega = TWOPI / (t[k] / tscale);
+                    bad = sgni(eval_secular(wave, omega, x).m) != want;
+                    // the answer the replay gave for the period: its last abscissa
+                    if (i == (int)S.roff[k + 1] - 1 && k != kfail) bad = bad || x != c[k];
+                }
+                const unsigned long long mask = __ballot(bad);
+                exec += (unsigned long long)__popcll(__ballot(act));
+                if (mask) {
+                    first_bad = base + (int)__ffsll((long long)mask) - 1;
+                    break;
+                }
+            }
+#else
+            // two abscissae per lane, neighbours of one period's search as a rule
+            for (int base = vbeg; base < npts; base += 128) {
+                const int i0 = base + 2 * lane, i1 = i0 + 1;
+                const bool act0 = i0 < npts, act1 = i1 < npts;
+                bool bad0 = false, bad1 = false;
+                if (act0) {
+                    const int k0 = period_of(i0);
+                    const int q0 = i0 - (int)S.roff[k0];
+                    const bool same = !act1 || i1 < (int)S.roff[k0 + 1];
+                    const int k1 = same ? k0 : k0 + 1;
+                    double x0, x1;
+                    replay_abscissae(k0, q0, dc, x0, x1);
+                    if (!same) x1 = S.rstart[k1];
+                    if (!act1) x1 = x0;
+                    const double omega0 = TWOPI / (t[k0] / tscale);
+                    const double omega1 = same ? omega0 : TWOPI / (t[k1] / tscale);
+                    const SecVal2 v = eval_secular2_inline(wave, omega0, x0, omega1, x1);
+                    const int want0 = (x0 <= S.lo[k0]) ? (int)S.slo[k0] : (int)S.shi[k0];
+                    const int want1 = (x1 <= S.lo[k1]) ? (int)S.slo[k1] : (int)S.shi[k1];
+                    bad0 = sgni(v.m0) != want0;
+                    bad1 = act1 && sgni(v.m1) != want1;
+                    // the answer the replay gave for the period: its last abscissa
+                    const int last0 = (int)S.roff[k0 + 1] - 1, last1 = (int)S.roff[k1 + 1] - 1;
+                    if (i0 == last0 && k0 != kfail) bad0 = bad0 || x0 != c[k0];
+                    if (act1 && i1 == last1 && k1 != kfail) bad1 = bad1 || x1 != c[k1];
+                }
+                const unsigned long long m0 = __ballot(bad0), m1 = __ballot(bad1);
+                exec += (unsigned long long)(__popcll(__ballot(act0)) + __popcll(__ballot(act1)));
+                if (m0 | m1) {
+                    const int f0 = m0 ? base + 2 * ((int)__ffsll((long long)m0) - 1) : npts;
+                    const int f1 = m1 ? base + 2 * ((int)__ffsll((long long)m1) - 1) + 1 : npts;
+                    first_bad = f0 < f1 ? f0 : f1;
+                    break;
+                }
+            }
+#endif
+    cnt.exec += exec;
+    return first_bad;
+}
+
 // ---- the curve ---------------------------------------------------------------
 // Fundamental-mode phase velocities c[0..P-1] (LDS) of the table in g_T, bit-identical to
 // phase_curve_wave(..., mode = 0, ...).  Returns MHD_ST_OK or MHD_ST_NOROOT.
@@ -1051,55 +1149,13 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
         if (kplain >= 0) CHAIN_EVENT(7)
 #endif
         PROF_ADD(2)
-        // the period abscissa i of this pass belongs to
-        auto period_of = [&](int i) -> int {
-            int a = kstart, b = kend - 1;
-            while (a < b) {
-                const int mid = (a + b + 1) >> 1;
-                if ((int)S.roff[mid] <= i) a = mid; else b = mid - 1;
-            }
-            return a;
-        };
+        auto period_of = [&](int i) -> int { return period_of_abscissa(i, kstart, kend); };
         // verify: really evaluate every abscissa the replay consumed
         int vbeg = 0, klit = kstart;  // first unverified abscissa; first period not yet counted
         bool again = false;           // replay again from kstart
         for (;;) {
-            int first_bad = npts;
-            // two abscissae per lane, neighbours of one period's search as a rule
-            for (int base = vbeg; base < npts; base += 128) {
-                const int i0 = base + 2 * lane, i1 = i0 + 1;
-                const bool act0 = i0 < npts, act1 = i1 < npts;
-                bool bad0 = false, bad1 = false;
-                if (act0) {
-                    const int k0 = period_of(i0);
-                    const int q0 = i0 - (int)S.roff[k0];
-                    const bool same = !act1 || i1 < (int)S.roff[k0 + 1];
-                    const int k1 = same ? k0 : k0 + 1;
-                    double x0, x1;
-                    replay_abscissae(k0, q0, dc, x0, x1);
-                    if (!same) x1 = S.rstart[k1];
-                    if (!act1) x1 = x0;
-                    const double omega0 = TWOPI / (t[k0] / tscale);
-                    const double omega1 = same ? omega0 : TWOPI / (t[k1] / tscale);
-                    const SecVal2 v = eval_secular2(wave, omega0, x0, omega1, x1);
-                    const int want0 = (x0 <= S.lo[k0]) ? (int)S.slo[k0] : (int)S.shi[k0];
-                    const int want1 = (x1 <= S.lo[k1]) ? (int)S.slo[k1] : (int)S.shi[k1];
-                    bad0 = sgni(v.m0) != want0;
-                    bad1 = act1 && sgni(v.m1) != want1;
-                    // the answer the replay gave for the period: its last abscissa
-                    const int last0 = (int)S.roff[k0 + 1] - 1, last1 = (int)S.roff[k1 + 1] - 1;
-                    if (i0 == last0 && k0 != kfail) bad0 = bad0 || x0 != c[k0];
-                    if (act1 && i1 == last1 && k1 != kfail) bad1 = bad1 || x1 != c[k1];
-                }
-                const unsigned long long m0 = __ballot(bad0), m1 = __ballot(bad1);
-                cnt.exec += (unsigned long long)(__popcll(__ballot(act0)) + __popcll(__ballot(act1)));
-                if (m0 | m1) {
-                    const int f0 = m0 ? base + 2 * ((int)__ffsll((long long)m0) - 1) : npts;
-                    const int f1 = m1 ? base + 2 * ((int)__ffsll((long long)m1) - 1) + 1 : npts;
-                    first_bad = f0 < f1 ? f0 : f1;
-                    break;
-                }
-            }
+            const int first_bad = verify_pass(wave, t, tscale, dc, c, kstart, kend, kfail, vbeg,
+                                              npts, cnt);
             PROF_ADD(3)
             if (first_bad == npts) break;
             // periods before the first wrong sign are exact
