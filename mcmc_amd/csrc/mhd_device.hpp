@@ -40,6 +40,14 @@ struct LayerTable {
     double cc;           // search floor: 0.9 * half-space Rayleigh velocity of the slowest layer
     double betmx;        // largest vs
     int L;
+    // The tail of the last period's halvings that solve_period_wave inferred from an
+    // interpolated root instead of evaluating it (see there): abscissae, the signs the
+    // inference gave them, the period's angular frequency.  Evaluated with the next period's
+    // first round, or by flush_deferred().
+    int pend_n;
+    int pend_want[8];
+    double pend_x[8];
+    double pend_omega;
 };
 
 // Out-of-line routines share one register budget: VGPRs + AGPRs <= 256, so that two waves fit
@@ -72,6 +80,13 @@ __device__ __forceinline__ int sgni(double x) { return (x > 0.0) - (x < 0.0); }
 // A condition that is the same in every lane, made visible as such: the branch on it is a
 // scalar branch instead of an exec-masked region.
 __device__ __forceinline__ bool uni(bool c) { return __ballot(c) != 0ull; }
+
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
 
 // A double that is the same in every lane, moved to scalar registers.
 __device__ __forceinline__ double uniform_value(double x)
@@ -535,6 +550,7 @@ __device__ inline void build_layer_table(LayerTable& T, const double* m, int n_l
         T.cc = cc;
         T.betmx = betmx;
         T.L = L;
+        T.pend_n = 0;
     }
     wave_sync();
 }
@@ -567,7 +583,8 @@ __device__ __forceinline__ double scan_next(double& c1, int& idir, double clow, 
 }
 
 // Bracket and refine one period (getsol), one wave.  All arguments are
-// wave-uniform.  s1st carries sign(del1st) between periods.  Returns success.
+// wave-uniform.  s1st carries sign(del1st) between periods.
+// Returns 1 (root found), 0 (the search fails) or, when deferring, -1 (see DEFER).
 //
 // Round 1 evaluates the first 8 scan abscissae (lanes 0..7) and, for each of the 7
 // cells between them, the 7 nodes of a 3-level midpoint tree (lanes 8..56): when the
@@ -577,19 +594,43 @@ __device__ __forceinline__ double scan_next(double& c1, int& idir, double clow, 
 //
 // max_levels < 100 stops the halving after that many levels (a predictor's use): br[] then
 // receives the bracket {c1, c2, sign at c1} and c1io its midpoint.
-__device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, double t1, double& c1io,
-                                         double clow, double dc, double cm, double betmx,
-                                         bool ifirst, int& s1st, EvalCount& cnt,
-                                         int max_levels = 1000, double* br = nullptr)
+//
+// DEFER: after the tree round that takes the bracket to 9 levels (1e-5 km/s wide, far below
+// the spacing of neighbouring modes) the root is taken by linear interpolation of the tracked
+// values at the bracket's ends, the remaining halvings (at most 7) follow from it without being
+// evaluated, and their abscissae with the signs inferred are left in the layer table's
+// pend_* fields: two rounds per period instead of three.  They are really evaluated in lanes
+// 57..63 of the first round of the NEXT call (any call evaluates what is pending), or by
+// flush_deferred(); a sign that is not the inferred one makes that call return -1 before it does
+// anything else (flush_deferred: false), and the caller redoes the period the tail belongs to
+// without defer and goes on from there.  Every abscissa of the sequential algorithm is thus
+// evaluated before a curve is returned.
+template <bool DEFER>
+__device__ __forceinline__ int solve_period_impl(int wave, double t1, double& c1io, double clow,
+                                                 double dc, double cm, double betmx, bool ifirst,
+                                                 int& s1st, EvalCount& cnt, int max_levels,
+                                                 double* br)
 {
+    constexpr bool defer = DEFER;
+    LayerTable& T = g_T;  // (the calling wave's table: the deferred tail lives beside it)
     const int lane = threadIdx.x & 63;
     const double omega = TWOPI / t1;
     double c1 = c1io, c2 = c1io;
     int idir = +1, s1 = 0, s2 = 0;
-    bool have1 = false, bracketed = false;
+    bool bracketed = false;
     int pre_levels = 0;               // halving levels already evaluated for the bracket
     unsigned long long pneg = 0, ppos = 0;
     int pbase = 0;                    // first lane of the bracket's 3-level tree
+    // tracked values (mantissa, binary exponent) at the bracket's ends c1 and c2, and at the end
+    // that was replaced last (c0), the third point of the interpolation
+    double f1m = 0.0, f2m = 0.0, f0m = 0.0, c0 = 0.0;
+    int f1e = 0, f2e = 0, f0e = 0;
+    bool have0 = false;
+    auto lane_value = [&](const SecVal& v, int l, double& m, int& e) {
+        if (!DEFER) return;
+        m = readlane_f64(v.m, l);
+        e = __builtin_amdgcn_readlane(v.e, l);
+    };
 
     // ---- first pass of the wave: 8 scan abscissae + 7 small trees (upward scan assumed) ----
     {
@@ -617,20 +658,38 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
             }
             x = 0.5 * (a + b);
         }
-        const bool act = lane < 57;
-        double del = 0.0;
-        if (act) del = secular(T, wave, omega, x);
-        const unsigned long long neg = __ballot(act && del < 0.0), pos = __ballot(act && del > 0.0);
-        cnt.exec += 57;
+        // the deferred tail of the period before, in the lanes the trees leave free
+        const int np = DEFER ? __builtin_amdgcn_readfirstlane(T.pend_n) : 0;
+        const bool pend = lane >= 57 && lane - 57 < np;
+        double om = omega;
+        int want = 0;
+        if (pend) {
+            x = T.pend_x[lane - 57];
+            want = T.pend_want[lane - 57];
+            om = T.pend_omega;
+        }
+        const bool act = lane < 57 || pend;
+        SecVal v = {0.0, 0};
+        if (act) v = eval_secular(wave, om, x);
+        const unsigned long long neg = __ballot(act && v.m < 0.0), pos = __ballot(act && v.m > 0.0);
+        cnt.exec += 57 + np;
+        if (np) {
+            const bool bad = pend && sgni(v.m) != want;
+            wave_sync();
+            if (lane == 0) T.pend_n = 0;
+            wave_sync();
+            if (__ballot(bad) != 0ull) return -1;
+        }
         s1 = mask_bit_sign(neg, pos, 0);
+        lane_value(v, 0, f1m, f1e);
         cnt.lit += 1;
-        have1 = true;
         if (ifirst) s1st = s1;
         idir = (ifirst || s1st * s1 >= 0) ? +1 : -1;
         if (idir > 0) {
             for (int j = 1; j < 8; ++j) {
                 c2 = scan_next(c1, idir, clow, dc);
                 s2 = mask_bit_sign(neg, pos, j);
+                lane_value(v, j, f2m, f2e);
                 cnt.lit += 1;
                 if (s1 != s2) {
                     bracketed = true;
@@ -642,10 +701,63 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
                 }
                 c1 = c2;
                 s1 = s2;
+                f1m = f2m;
+                f1e = f2e;
                 if (uni(c1 < cm || c1 >= betmx + dc)) {
                     if (br) br[2] = (double)s1;
-                    return false;
+                    return 0;
                 }
+            }
+        }
+        if (bracketed) {
+            // the three levels of the bracket's own tree, with this round's values still in
+            // the lanes: c1 / c2 / s1 and the values at the ends
+            double c3;
+            int nctrl0 = 2, levels0 = 0;
+            int node = 1;
+            bool done0 = false;
+            while (node < 8) {
+                c3 = 0.5 * (c1 + c2);
+                const int s3 = mask_bit_sign(pneg, ppos, pbase + node - 1);
+                double m3;
+                int e3;
+                lane_value(v, pbase + node - 1, m3, e3);
+                cnt.lit += 1;
+                have0 = true;
+                if (s3 * s1 < 0) {
+                    c0 = c2;
+                    f0m = f2m;
+                    f0e = f2e;
+                    c2 = c3;
+                    f2m = m3;
+                    f2e = e3;
+                    node = 2 * node;
+                } else {
+                    c0 = c1;
+                    f0m = f1m;
+                    f0e = f1e;
+                    c1 = c3;
+                    s1 = s3;
+                    f1m = m3;
+                    f1e = e3;
+                    node = 2 * node + 1;
+                }
+                if (uni(fabs(c1 - c2) <= 1.0e-6 * c1) || ++levels0 >= max_levels) {
+                    done0 = true;
+                    break;
+                }
+                ++nctrl0;
+            }
+            pre_levels = levels0;
+            if (done0) {
+                if (br) {
+                    br[0] = c1;
+                    br[1] = c2;
+                    br[2] = (double)s1;
+                    c3 = 0.5 * (c1 + c2);
+                }
+                c1io = c3;
+                return uni(c3 <= betmx) ? 1 : 0;
             }
         }
     }
@@ -658,12 +770,13 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
             pt = scan_next(pc1, pdir, clow, dc);
             pc1 = pt;
         }
-        const double del = secular(T, wave, omega, pt);
-        const unsigned long long neg = __ballot(del < 0.0), pos = __ballot(del > 0.0);
+        const SecVal v = eval_secular(wave, omega, pt);
+        const unsigned long long neg = __ballot(v.m < 0.0), pos = __ballot(v.m > 0.0);
         cnt.exec += 64;
         for (int j = 0; j < 64; ++j) {
             c2 = scan_next(c1, idir, clow, dc);
             s2 = mask_bit_sign(neg, pos, j);
+            lane_value(v, j, f2m, f2e);
             cnt.lit += 1;
             if (s1 != s2) {
                 bracketed = true;
@@ -671,38 +784,20 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
             }
             c1 = c2;
             s1 = s2;
+            f1m = f2m;
+            f1e = f2e;
             if (uni(c1 < cm || c1 >= betmx + dc)) {
-                    if (br) br[2] = (double)s1;
-                    return false;
-                }
+                if (br) br[2] = (double)s1;
+                return 0;
+            }
         }
     }
 
     // ---- refine: pure interval halving ----
     double c3 = 0.0;
-    int nctrl = 2, levels = 0;
+    int levels = pre_levels, nctrl = 2 + pre_levels;
     bool done = false;
-    if (pre_levels) {
-        int node = 1;
-        while (node < 8) {
-            c3 = 0.5 * (c1 + c2);
-            const int s3 = mask_bit_sign(pneg, ppos, pbase + node - 1);
-            cnt.lit += 1;
-            if (s3 * s1 < 0) {
-                c2 = c3;
-                node = 2 * node;
-            } else {
-                c1 = c3;
-                s1 = s3;
-                node = 2 * node + 1;
-            }
-            if (uni(fabs(c1 - c2) <= 1.0e-6 * c1) || ++levels >= max_levels) {
-                done = true;
-                break;
-            }
-            ++nctrl;
-        }
-    }
+    int tree_rounds = 0;
     while (!done) {
         double a = c1, b = c2;
         const int t = lane ? lane : 1;
@@ -712,13 +807,17 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
             if ((t >> lvl) & 1) a = mid; else b = mid;
         }
         const double pt = 0.5 * (a + b);
-        const double del = secular(T, wave, omega, pt);
-        const unsigned long long neg = __ballot(del < 0.0), pos = __ballot(del > 0.0);
+        const SecVal v = eval_secular(wave, omega, pt);
+        const unsigned long long neg = __ballot(v.m < 0.0), pos = __ballot(v.m > 0.0);
         cnt.exec += 64;
+        ++tree_rounds;
         int node = 1;
         while (node < 64) {
             c3 = 0.5 * (c1 + c2);
             const int s3 = mask_bit_sign(neg, pos, node);
+            double m3;
+            int e3;
+            lane_value(v, node, m3, e3);
             cnt.lit += 1;
             // the sequential loop applies at most 98 updates; the 99th midpoint is
             // evaluated and returned without being applied
@@ -726,12 +825,23 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
                 done = true;
                 break;
             }
+            have0 = true;
             if (s3 * s1 < 0) {
+                c0 = c2;
+                f0m = f2m;
+                f0e = f2e;
                 c2 = c3;
+                f2m = m3;
+                f2e = e3;
                 node = 2 * node;
             } else {
+                c0 = c1;
+                f0m = f1m;
+                f0e = f1e;
                 c1 = c3;
                 s1 = s3;
+                f1m = m3;
+                f1e = e3;
                 node = 2 * node + 1;
             }
             if (uni(fabs(c1 - c2) <= 1.0e-6 * c1) || ++levels >= max_levels) {
@@ -740,6 +850,64 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
             }
             ++nctrl;
         }
+        if (done || !defer || max_levels < 1000 || tree_rounds > 1) continue;
+        // ---- the rest of the halvings from the interpolated root, to be verified later ----
+        if (!(f1m != 0.0 && f2m != 0.0 && (f1m < 0.0) != (f2m < 0.0))) continue;
+        int de = f2e - f1e;
+        de = de > 1000 ? 1000 : (de < -1000 ? -1000 : de);
+        const double rho = ldexp(f2m / f1m, de);  // negative
+        double root = c1 + (c2 - c1) / (1.0 - rho);
+        if (have0) {
+            // inverse quadratic interpolation through the three points (values on f1's scale);
+            // taken if it lands inside the bracket
+            int d0 = f0e - f1e;
+            d0 = d0 > 1000 ? 1000 : (d0 < -1000 ? -1000 : d0);
+            const double g1 = f1m, g2 = ldexp(f2m, de), g0 = ldexp(f0m, d0);
+            const double q = c0 * (g1 * g2) / ((g0 - g1) * (g0 - g2)) +
+                             c1 * (g0 * g2) / ((g1 - g0) * (g1 - g2)) +
+                             c2 * (g0 * g1) / ((g2 - g0) * (g2 - g1));
+            if (uni(q > fmin(c1, c2) && q < fmax(c1, c2))) root = q;
+        }
+        const bool below1 = uni(c1 <= root);
+        double d1 = c1, d2 = c2, d3 = c3, px = 0.0;
+        int ds1 = s1, n = 0, dctrl = nctrl, pw = 0;
+        bool settled = false;
+        while (n < 7) {
+            d3 = 0.5 * (d1 + d2);
+            const bool same = uni((d3 <= root) == below1);
+            const int s3 = same ? ds1 : -ds1;
+            if (lane == 57 + n) {
+                px = d3;
+                pw = s3;
+            }
+            ++n;
+            if (dctrl >= 100) {
+                settled = true;
+                break;
+            }
+            if (same) d1 = d3; else d2 = d3;
+            if (uni(fabs(d1 - d2) <= 1.0e-6 * d1)) {
+                settled = true;
+                break;
+            }
+            ++dctrl;
+        }
+        if (!settled) continue;  // more than 7 halvings left: by another tree round
+        wave_sync();
+        if (lane >= 57 && lane - 57 < n) {
+            T.pend_x[lane - 57] = px;
+            T.pend_want[lane - 57] = pw;
+        }
+        if (lane == 0) {
+            T.pend_n = n;
+            T.pend_omega = omega;
+        }
+        wave_sync();
+        // (counted with the period they belong to; a caller that has to search the period again
+        // takes the period's whole count back)
+        cnt.lit += n;
+        c3 = d3;
+        done = true;
     }
     if (br) {
         br[0] = c1;
@@ -748,7 +916,48 @@ __device__ MHD_NOINLINE bool solve_period_wave(const LayerTable& T, int wave, do
         c3 = 0.5 * (c1 + c2);
     }
     c1io = c3;
-    return uni(c3 <= betmx);
+    return uni(c3 <= betmx) ? 1 : 0;
+}
+
+__device__ MHD_NOINLINE bool solve_period_wave(const LayerTable&, int wave, double t1, double& c1io,
+                                         double clow, double dc, double cm, double betmx,
+                                         bool ifirst, int& s1st, EvalCount& cnt,
+                                         int max_levels = 1000, double* br = nullptr)
+{
+    return solve_period_impl<false>(wave, t1, c1io, clow, dc, cm, betmx, ifirst, s1st, cnt,
+                                    max_levels, br) > 0;
+}
+
+// The same search leaving a deferred tail (and verifying the one it finds): 1, 0 or -1 as above.
+__device__ MHD_NOINLINE int solve_period_deferring(int wave, double t1, double& c1io, double clow,
+                                             double dc, double cm, double betmx, bool ifirst,
+                                             int& s1st, EvalCount& cnt)
+{
+    return solve_period_impl<true>(wave, t1, c1io, clow, dc, cm, betmx, ifirst, s1st, cnt, 1000,
+                                   nullptr);
+}
+
+// Really evaluates the tail a deferring solve_period_wave left (if any).  false: a sign is not
+// the inferred one, the period it belongs to has to be searched again without defer.
+__device__ MHD_NOINLINE bool flush_deferred(int wave, EvalCount& cnt)
+{
+    LayerTable& T = g_T;
+    const int lane = threadIdx.x & 63;
+    const int np = __builtin_amdgcn_readfirstlane(T.pend_n);
+    if (np == 0) return true;
+    const bool pend = lane < np;
+    SecVal v = {0.0, 0};
+    int want = 0;
+    if (pend) {
+        want = T.pend_want[lane];
+        v = eval_secular(wave, T.pend_omega, T.pend_x[lane]);
+    }
+    const bool bad = pend && sgni(v.m) != want;
+    cnt.exec += np;
+    wave_sync();
+    if (lane == 0) T.pend_n = 0;
+    wave_sync();
+    return __ballot(bad) == 0ull;
 }
 
 // One phase-velocity curve (getc) for the table in T; t[] ascending periods,
@@ -764,6 +973,9 @@ __device__ MHD_NOINLINE int phase_curve_wave(const LayerTable& T, int wave, cons
     dc = fabs(dc);
     const double one = 1.0e-2, onea = 1.5;
     double c1 = cc, clow = cc;
+    // the sequential algorithm's evaluation count before the search of the current period and of
+    // the one before (a period that is searched again must not be counted twice)
+    unsigned long long lit_cur = cnt.lit, lit_prev = cnt.lit;
     for (int k = kstart; k < P; ++k) c[k] = 0.0;
     for (int iq = 0; iq <= mode; ++iq) {
         for (int k = (iq == 0 ? kstart : 0); k < P; ++k) {
@@ -790,14 +1002,43 @@ __device__ MHD_NOINLINE int phase_curve_wave(const LayerTable& T, int wave, cons
                 clow = cm;
                 c1 = c[k - 1] - onea * dc;
             }
-            const bool ok = solve_period_wave(T, wave, t[k] / tscale, c1, clow, dc, cm, betmx,
-                                              ifirst, s1st, cnt);
+            // the fundamental mode is searched with deferred tails (two rounds per period)
+            const bool defer = (iq == 0);
+            lit_prev = lit_cur;
+            lit_cur = cnt.lit;
+            const int ok = defer ? solve_period_deferring(wave, t[k] / tscale, c1, clow, dc, cm, betmx,
+                                                          ifirst, s1st, cnt)
+                                 : (int)solve_period_wave(T, wave, t[k] / tscale, c1, clow, dc, cm,
+                                                          betmx, ifirst, s1st, cnt);
+            if (ok < 0) {
+                // the tail inferred for period k-1 was wrong: that period again, every halving
+                // evaluated, then this one from its true start
+                const int kp = k - 1;
+                cnt.lit = lit_prev;
+                lit_cur = lit_prev;
+                double cp = (kp == 0) ? cc : c[kp - 1] - onea * dc;
+                if (!solve_period_wave(T, wave, t[kp] / tscale, cp, (kp == 0) ? cc : cm, dc, cm,
+                                       betmx, kp == 0, s1st, cnt))
+                    return MHD_ST_NOROOT;
+                c[kp] = cp;
+                --k;
+                continue;
+            }
             if (!ok) {
                 if (iq == 0) return MHD_ST_NOROOT;
                 for (int i = k; i < P; ++i) c[i] = 0.0;
                 break;
             }
             c[k] = c1;
+            if (defer && k == P - 1 && !flush_deferred(wave, cnt)) {
+                // the last period's tail: the same repair
+                cnt.lit = lit_cur;
+                double cp = (k == 0) ? cc : c[k - 1] - onea * dc;
+                if (!solve_period_wave(T, wave, t[k] / tscale, cp, (k == 0) ? cc : cm, dc, cm,
+                                       betmx, k == 0, s1st, cnt))
+                    return MHD_ST_NOROOT;
+                c[k] = cp;
+            }
         }
     }
     return MHD_ST_OK;

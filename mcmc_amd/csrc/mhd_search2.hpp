@@ -830,13 +830,6 @@ struct ReplayPass {
     int npts;    // abscissae consumed by the periods replayed
 };
 
-__device__ __forceinline__ double readlane_f64(double v, int l)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
 // Scan and halvings of one plain period.  BELOW: the start lies on the root's lower side (the scan
 // goes upward); otherwise on its upper side (it goes downward).  c1 is the end of the bracket on
 // the start's side throughout.  Written once per side so that a halving is an add, a multiply,
