@@ -121,7 +121,8 @@ def main():
                     help="2 = two candidates per chain in flight (default), 1 = one")
     # other configurations of the same path (the headline metric is the default of each)
     ap.add_argument("--layers", type=int, default=N_LAYERS)
-    ap.add_argument("--itype", choices=["phase", "group"], default="phase")
+    ap.add_argument("--itype", default="phase",
+                    choices=["phase", "group", "phase+group", "phase+ellipticity", "ellipticity"])
     ap.add_argument("--wave", choices=["rayleigh", "love"], default="rayleigh")
     ap.add_argument("--rotation", choices=["off", "on"], default="off",
                     help="on: rotated-frame proposals and covariance accumulation every step")
@@ -164,7 +165,8 @@ def main():
     true_curve, st = prob0.forward(torch.tensor(true_model(nl)[None, :], device=prob0.device))
     assert int(st[0]) == 0
     np.random.seed(0)
-    obs = true_curve[0].cpu().numpy() + STD * np.random.randn(N_PERIODS)
+    obs = true_curve[0].cpu().numpy()
+    obs = obs + STD * np.random.randn(N_PERIODS if args.itype == "phase" else len(obs))
     prob = DeviceProblem(nl, VPVS, periods, obs, "normal", {"std": STD}, bounds, **kind)
     rng = np.random.default_rng(1000 + rank)
     starts = prior_starts(prob, bounds, B, rng)
@@ -249,7 +251,7 @@ def main():
                       f"{world * B // args.temps} ladders, {B} replicas per GPU, exchange sweep "
                       f"(all-gather of logL + device sweep) every {args.thin} steps"
                       if args.tempering else
-                      f"MH steps/sec (whole node), {nl}-layer {args.wave} {args.itype} velocity, "
+                      f"MH steps/sec (whole node), {nl}-layer {args.wave}, datum {args.itype}, "
                       f"{B} chains x 40 periods, rotation {args.rotation}",
             "value": world * B * K / elapsed,
             "unit": "MH steps/s",

@@ -57,6 +57,15 @@ extern "C" {
 #define MHD_PHASE 0
 #define MHD_GROUP 1
 #define MHD_PHASE_AND_GROUP 2 /* both curves as one datum of length 2P: [phase, group] */
+/* Rayleigh-wave ellipticity ur/uz at the free surface, evaluated at each period's phase velocity
+ * (positive = retrograde motion; 0 where the mode has no root at that period), as the second half
+ * of a joint datum of length 2P [phase, ellipticity], or alone.  The reference names the datum
+ * (README.md:4) and holds an empty EllipticityParams class (src/inversion/model_params.py:212-213)
+ * but no call site and no values: PARITY UNPINNED; the values are checked against this
+ * repository's oracle, and the oracle against an independent propagator-matrix solution.  Not
+ * defined for Love waves (MHD_EINVAL). */
+#define MHD_PHASE_AND_ELL 3
+#define MHD_ELL 4
 #define MHD_NORMAL 0
 #define MHD_ASYM_LAPLACE 1
 
@@ -77,10 +86,12 @@ typedef struct mhd_problem {
     int32_t n_layers;   /* finite layers; NP = 2*n_layers+1 parameters =
                            [n_layers interface depths, n_layers+1 vs]   */
     int32_t n_periods;  /* P; the data vectors (obs, pred, noise) have ND = P entries, or
-                           2P for MHD_PHASE_AND_GROUP (then P <= MHD_MAX_PERIODS / 2)  */
+                           2P for MHD_PHASE_AND_GROUP and MHD_PHASE_AND_ELL (then
+                           P <= MHD_MAX_PERIODS / 2)                                  */
     int32_t wave;       /* MHD_RAYLEIGH | MHD_LOVE  (disba wave=)        */
     int32_t mode;       /* 0 = fundamental          (disba mode=)        */
-    int32_t itype;      /* MHD_PHASE | MHD_GROUP | MHD_PHASE_AND_GROUP           */
+    int32_t itype;      /* MHD_PHASE | MHD_GROUP | MHD_PHASE_AND_GROUP |
+                           MHD_PHASE_AND_ELL | MHD_ELL                           */
     int32_t noise_dist; /* MHD_NORMAL | MHD_ASYM_LAPLACE                 */
     int32_t n_noise_a;  /* 1 or ND: length of noise_a                    */
     int32_t n_noise_b;  /* 1 or ND: length of noise_b                    */

@@ -15,7 +15,7 @@ c_int32, c_double, c_void_p = ctypes.c_int32, ctypes.c_double, ctypes.c_void_p
 
 ST_OK, ST_BOUNDS, ST_PHYSICS, ST_NOROOT, ST_ZERODIV = 0, 1, 2, 3, 4
 RAYLEIGH, LOVE = 0, 1
-PHASE, GROUP, PHASE_AND_GROUP = 0, 1, 2
+PHASE, GROUP, PHASE_AND_GROUP, PHASE_AND_ELL, ELL = 0, 1, 2, 3, 4
 NORMAL, ASYM_LAPLACE = 0, 1
 ROT_ACCUMULATE, ROT_FRAME = 1, 2
 MAX_LAYERS, MAX_PERIODS = 15, 128

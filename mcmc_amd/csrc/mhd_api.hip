@@ -35,10 +35,11 @@ int check_problem(const mhd_problem_t* p, bool need_data)
     if (p->n_periods < 1 || p->n_periods > MHD_MAX_PERIODS)
         return fail(MHD_EINVAL, "n_periods outside 1..MHD_MAX_PERIODS");
     if (p->wave != MHD_RAYLEIGH && p->wave != MHD_LOVE) return fail(MHD_EINVAL, "bad wave");
-    if (p->itype != MHD_PHASE && p->itype != MHD_GROUP && p->itype != MHD_PHASE_AND_GROUP)
-        return fail(MHD_EINVAL, "bad itype");
-    if (p->itype == MHD_PHASE_AND_GROUP && 2 * p->n_periods > MHD_MAX_PERIODS)
-        return fail(MHD_EINVAL, "phase and group together: 2 * n_periods beyond MHD_MAX_PERIODS");
+    if (p->itype < MHD_PHASE || p->itype > MHD_ELL) return fail(MHD_EINVAL, "bad itype");
+    if (data_length(*p) > MHD_MAX_PERIODS)
+        return fail(MHD_EINVAL, "a joint datum: 2 * n_periods beyond MHD_MAX_PERIODS");
+    if ((p->itype == MHD_PHASE_AND_ELL || p->itype == MHD_ELL) && p->wave != MHD_RAYLEIGH)
+        return fail(MHD_EINVAL, "ellipticity is a property of Rayleigh waves");
     if (p->mode < 0 || p->mode > 64) return fail(MHD_EINVAL, "bad mode");
     if (!(p->dc > 0.0) && !(p->dc < 0.0)) return fail(MHD_EINVAL, "dc must be non-zero");
     if (!p->periods) return fail(MHD_EINVAL, "periods is NULL");
@@ -344,7 +345,9 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     EvalCount cnt = {0, 0};
     // a chain whose curves keep defeating the predictor (densely spaced modes) uses the
     // wave-sequential search for a while, then tries the predictor again
-    SearchPolicy policy = {search == 2 ? 0 : 3, 0, p.itype == MHD_PHASE ? 0 : 3};
+    // (the chain's current phase curve guides the predictor when the chain keeps one)
+    const bool phase_hint = p.itype == MHD_PHASE || p.itype == MHD_PHASE_AND_ELL;
+    SearchPolicy policy = {search == 2 ? 0 : 3, 0, phase_hint ? 0 : 3};
     __syncthreads();
 
     for (int s = 0; s < S; ++s) {
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred,
                                        scratch, cnt, policy.stepwise(), pred, pred,
-                                       p.itype != MHD_PHASE ? 0 : (fabs(cz) <= hlim[kk] ? 2 : 1));
+                                       !phase_hint ? 0 : (fabs(cz) <= hlim[kk] ? 2 : 1));
                 if (lane == 0)
                     hint_limit_update(hlim, kk, cz, __builtin_amdgcn_readfirstlane(g_PS.hinted));
                 if (search == 2)
@@ -738,7 +741,11 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     // how the curves of this chain are searched (see SearchPolicy); a chain goes on at the
     // level its last launch ended with
     const bool keeps = ch.sched && B <= SCHED_MAX_CHAINS;
-    SearchPolicy policy = {search == 2 ? 0 : 3, 0, p.itype == MHD_PHASE ? 0 : 3};
+    // the chain's current phase curve guides the predictor when the chain keeps one; for group
+    // velocity the two phase curves behind it do (ghint)
+    const bool phase_hint = p.itype == MHD_PHASE || p.itype == MHD_PHASE_AND_ELL;
+    const bool group_kind = p.itype == MHD_GROUP || p.itype == MHD_PHASE_AND_GROUP;
+    SearchPolicy policy = {search == 2 ? 0 : 3, 0, phase_hint ? 0 : 3};
     if (search == 2 && keeps) {
         int lv = (int)sched_view(ch.sched, B).level[ib] & 3;
         if (lv > policy.max_level) lv = policy.max_level;
@@ -760,7 +767,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     // chain's first wave computes them once per launch (and on every acceptance they are the
     // candidate's).
     if (writer && lane == 0) ghint_ok_[g] = 0;
-    if (p.itype != MHD_PHASE && p.mode == 0 && search == 2 && writer) {
+    if (group_kind && p.mode == 0 && search == 2 && writer) {
         wave_sync();
         build_layer_table(T, m, nl, p.vpvs, lane, nlmax);
         EvalCount extra = {0, 0};
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         wave_sync();
     }
     group_sync();
-    const bool hinted = p.mode == 0 && (p.itype == MHD_PHASE || ghint_ok_[g] != 0);
+    const bool hinted = p.mode == 0 && (phase_hint || ghint_ok_[g] != 0);
     if (search == 2 && hinted) {
         policy.max_level = HINTED_MAX_LEVEL;
         if (policy.level > policy.max_level) {
@@ -833,7 +840,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
                         mn[lane] = (m[lane] - lo[lane]) / rg[lane];
                     }
                     for (int k = lane; k < ND; k += 64) pred[k] = newpred[c][k];
-                    if (p.itype != MHD_PHASE)
+                    if (group_kind)
                         for (int k = lane; k < 2 * P; k += 64) ghint[k] = scratch[c][k];
                     wave_sync();
                 }

@@ -142,9 +142,11 @@ __device__ __forceinline__ void osc_or_evan(double k, double xk, double dpth, do
 // Rayleigh period equation (Dunkin compound matrix).  Returns the first
 // component of the propagated, rescaled vector; *scale_exp receives the sum of
 // the binary exponents taken out, so that value * 2^(*scale_exp) is the
-// unscaled (smooth) secular function up to one positive constant.
-__device__ __forceinline__ double secular_rayleigh(const LayerTable& T, double omega,
-                                                   double inv_om2, double c, int* scale_exp)
+// unscaled (smooth) secular function up to one positive constant.  rest, if given, receives
+// the other four components at the surface (on the same scale).
+__device__ __forceinline__ double rayleigh_compound(const LayerTable& T, double omega,
+                                                    double inv_om2, double c, int* scale_exp,
+                                                    double* rest)
 {
     const int L = T.L;
     const double k = omega / c;
@@ -220,7 +222,19 @@ __device__ __forceinline__ double secular_rayleigh(const LayerTable& T, double o
         e4 = ldexp(n4, -ex);
     }
     if (scale_exp) *scale_exp = sexp;
+    if (rest) {
+        rest[0] = e1;
+        rest[1] = e2;
+        rest[2] = e3;
+        rest[3] = e4;
+    }
     return e0;
+}
+
+__device__ __forceinline__ double secular_rayleigh(const LayerTable& T, double omega,
+                                                   double inv_om2, double c, int* scale_exp)
+{
+    return rayleigh_compound(T, omega, inv_om2, c, scale_exp, nullptr);
 }
 
 __device__ __forceinline__ double secular_love(const LayerTable& T, double omega, double c,
@@ -269,6 +283,26 @@ __device__ MHD_NOINLINE SecVal eval_secular(int wave, double omega, double c)
     else
         v.m = secular_rayleigh(g_T, omega, 1.0 / (omega * omega), c, &v.e);
     return v;
+}
+
+// Rayleigh-wave ellipticity ur/uz at the free surface for phase velocity c.  Numbering the
+// motion-stress components 1 = ur, 2 = uz, 3 = normal stress, 4 = shear stress, the compound
+// vector holds the minors e0 = Y34, e1 = Y24, e2 = Y14 / k = -Y23 / k, e3 = Y13, e4 = Y12 of the
+// two solutions that decay in the half-space.  The combination free of shear stress at the
+// surface has ur : uz = Y14 : Y24, the one free of normal stress Y13 : Y23; on a root of the
+// period equation (Y34 = 0) they are one solution and the ratios agree.  The better conditioned
+// one is taken: Y13 / Y23 next to a pole (uz = 0, |ur/uz| > 1), Y14 / Y24 next to a zero.
+// Positive for retrograde motion (a homogeneous Poisson half-space gives +0.6812).  The
+// reference only names this datum (README.md:4, the empty EllipticityParams of
+// src/inversion/model_params.py:212-213): there are no reference values for it.
+__device__ MHD_NOINLINE double eval_ellipticity(double omega, double c)
+{
+    omega = fmax(omega, 1.0e-4);
+    double r[4];
+    int se;
+    rayleigh_compound(g_T, omega, 1.0 / (omega * omega), c, &se, r);
+    const double k = omega / c;
+    return (fabs(r[0]) >= fabs(r[2])) ? -k * r[1] / r[0] : r[2] / (k * r[1]);
 }
 
 // Two abscissae in one lane: the same operations as secular_rayleigh for each, written side by
@@ -1044,14 +1078,38 @@ __device__ MHD_NOINLINE int phase_curve_wave(const LayerTable& T, int wave, cons
     return MHD_ST_OK;
 }
 
+// The ellipticity at each period's phase velocity c[k] (0 where the mode has no root), one
+// period per lane; c and ell in LDS.
+__device__ inline void ellipticity_curve(const double* t, int P, const double* c, double* ell)
+{
+    const int lane = threadIdx.x & 63;
+    wave_sync();
+    for (int k0 = 0; k0 < P; k0 += 64) {
+        const int k = k0 + lane;
+        double v = 0.0;
+        if (k < P && c[k] > 0.0) v = eval_ellipticity(TWOPI / t[k], c[k]);
+        if (k < P) ell[k] = v;
+    }
+    wave_sync();
+}
+
 // forward_model for the table in T: phase or group velocity into vel[] (LDS), or both
-// (MHD_PHASE_AND_GROUP: phase in vel[0..P), group in vel[P..2P)).
+// (MHD_PHASE_AND_GROUP: phase in vel[0..P), group in vel[P..2P)), or phase velocity and
+// ellipticity (MHD_PHASE_AND_ELL: phase in vel[0..P), ellipticity in vel[P..2P)), or the
+// ellipticity alone (MHD_ELL).
 // scratch must hold 2*P doubles (LDS).  Wave-uniform.
 __device__ inline int forward_wave(const LayerTable& T, int wave, int mode, int itype,
                                    const double* t, int P, double dc, double dt, double* vel,
                                    double* scratch, EvalCount& cnt)
 {
     if (itype == MHD_PHASE) return phase_curve_wave(T, wave, t, P, 1.0, mode, dc, vel, cnt);
+    if (itype == MHD_PHASE_AND_ELL || itype == MHD_ELL) {
+        double* c = (itype == MHD_ELL) ? scratch : vel;
+        const int st0 = phase_curve_wave(T, wave, t, P, 1.0, mode, dc, c, cnt);
+        if (st0 != MHD_ST_OK) return st0;
+        ellipticity_curve(t, P, c, (itype == MHD_ELL) ? vel : vel + P);
+        return MHD_ST_OK;
+    }
     if (itype == MHD_PHASE_AND_GROUP) {
         const int st0 = phase_curve_wave(T, wave, t, P, 1.0, mode, dc, vel, cnt);
         if (st0 != MHD_ST_OK) return st0;
@@ -1103,7 +1161,8 @@ __device__ inline double npsum_small(const double* a, int n)
 // Entries of the data vectors (obs, pred, noise) of a problem.
 __device__ __host__ inline int data_length(const mhd_problem_t& p)
 {
-    return p.itype == MHD_PHASE_AND_GROUP ? 2 * p.n_periods : p.n_periods;
+    return (p.itype == MHD_PHASE_AND_GROUP || p.itype == MHD_PHASE_AND_ELL) ? 2 * p.n_periods
+                                                                             : p.n_periods;
 }
 
 // Model.get_likelihood for one predicted curve in LDS; term[] is LDS scratch [ND].

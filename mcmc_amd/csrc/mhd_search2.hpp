@@ -1288,7 +1288,8 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
 }
 
 // forward_model with the period-parallel curve where it applies (fundamental mode).
-// hint: the phase curve of a similar model (MHD_PHASE, MHD_PHASE_AND_GROUP); hint2: its two
+// hint: the phase curve of a similar model (MHD_PHASE, MHD_PHASE_AND_GROUP, MHD_PHASE_AND_ELL,
+// MHD_ELL); hint2: its two
 // phase curves at t/(1+dt) and t/(1-dt), P values each (MHD_GROUP, MHD_PHASE_AND_GROUP).
 __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode, int itype,
                                         const double* t, int P, double dc, double dt,
@@ -1306,6 +1307,13 @@ __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode,
         }
         wave_sync();
         return forward_wave(T, wave, mode, itype, t, P, dc, dt, vel, scratch, cnt);
+    }
+    if (itype == MHD_PHASE_AND_ELL || itype == MHD_ELL) {
+        double* c = (itype == MHD_ELL) ? scratch : vel;
+        const int st = phase_curve_predicted(wave, t, P, 1.0, dc, c, cnt, stepwise, hint, use_hint);
+        if (st != MHD_ST_OK) return st;
+        ellipticity_curve(t, P, c, (itype == MHD_ELL) ? vel : vel + P);
+        return MHD_ST_OK;
     }
     int trouble = 0;
     if (itype != MHD_GROUP) {

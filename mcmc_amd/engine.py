@@ -66,13 +66,14 @@ class DeviceProblem:
         self.n_layers = int(n_layers)
         self.NP = 2 * self.n_layers + 1
         self.search, self.candidates = int(search), int(candidates)
-        itype_code = {"phase": L.PHASE, "group": L.GROUP, "phase+group": L.PHASE_AND_GROUP}[itype]
+        itype_code = {"phase": L.PHASE, "group": L.GROUP, "phase+group": L.PHASE_AND_GROUP,
+                      "phase+ellipticity": L.PHASE_AND_ELL, "ellipticity": L.ELL}[itype]
         with torch.cuda.device(self.device):
             L.check(L.lib().mhd_init(self.device.index))
         periods = np.ascontiguousarray(periods, dtype=np.float64)
         self.P = len(periods)
-        # entries of the data vectors: the phase curve, the group curve, or both in a row
-        self.ND = 2 * self.P if itype == "phase+group" else self.P
+        # entries of the data vectors: one curve, or two in a row
+        self.ND = 2 * self.P if itype in ("phase+group", "phase+ellipticity") else self.P
         if self.n_layers < 1 or self.n_layers > L.MAX_LAYERS:
             raise ValueError("n_layers outside the compiled limit")
         if self.P < 1 or self.ND > L.MAX_PERIODS:

@@ -22,7 +22,8 @@ class DispersionCurveParams(ModelParams):
     vp = vs * vpvs_ratio and density follows Gardner's relation.  forward_model runs the HIP
     kernel; wave / mode / itype select what disba's PhaseDispersion / GroupDispersion would be
     asked for (the reference always uses Rayleigh, mode 0, phase velocity); itype
-    "phase+group" predicts both curves as one datum of twice the length.
+    "phase+group" predicts both curves as one datum of twice the length, "phase+ellipticity"
+    the phase curve followed by the Rayleigh-wave ellipticity at each period.
     """
 
     def __init__(self, n_layers, param_bounds, proposal_width, vpvs_ratio, wave="rayleigh",
@@ -128,6 +129,19 @@ class DispersionCurveParams(ModelParams):
         return vel[0]
 
 
-class EllipticityParams(ModelParams):
-    """Placeholder, as in the reference (src/inversion/model_params.py:212-213)."""
-    pass
+class EllipticityParams(DispersionCurveParams):
+    """The layered model observed through its Rayleigh-wave ellipticity spectrum.
+
+    The reference announces this datum (README.md:4) and holds an empty class of this name
+    (src/inversion/model_params.py:212-213); there is no forward model for it there and no
+    value to compare with.  Here it is the same parameterisation as DispersionCurveParams
+    whose forward model returns ur/uz at the free surface (positive for retrograde motion) at
+    each period's phase velocity: after the phase-velocity curve when joint (the datum of a
+    joint dispersion + ellipticity likelihood, 2 * n_periods entries), or alone.
+    """
+
+    def __init__(self, n_layers, param_bounds, proposal_width, vpvs_ratio, mode=0, joint=True,
+                 dc=0.005):
+        super().__init__(n_layers, param_bounds, proposal_width, vpvs_ratio, wave="rayleigh",
+                         mode=mode, itype="phase+ellipticity" if joint else "ellipticity", dc=dc)
+        self.joint = joint

@@ -40,6 +40,10 @@ def lib():
         L = ctypes.CDLL(_SO)
         L.orc_secular.restype = c_double
         L.orc_secular.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_double, c_double]
+        L.orc_compound.restype = None
+        L.orc_compound.argtypes = [_dp, _dp, _dp, _dp, c_int, c_double, c_double, _dp]
+        L.orc_ellipticity.restype = c_double
+        L.orc_ellipticity.argtypes = [_dp, _dp, _dp, _dp, c_int, c_double, c_double]
         L.orc_dispersion.argtypes = [_dp, _dp, _dp, _dp, c_int, _dp, c_int, c_int, c_int, c_int,
                                      c_double, c_double, _dp, _llp]
         L.orc_layer_table.restype = None
@@ -87,9 +91,23 @@ def secular(d, a, b, rho, period, c, wave=0):
     return lib().orc_secular(_d(d), _d(a), _d(b), _d(rho), len(d), wave, float(period), float(c))
 
 
+def compound(d, a, b, rho, period, c):
+    """The Rayleigh compound vector (5 minors) at the free surface."""
+    d, a, b, rho = map(_f64, (d, a, b, rho))
+    e = np.zeros(5)
+    lib().orc_compound(_d(d), _d(a), _d(b), _d(rho), len(d), float(period), float(c), _d(e))
+    return e
+
+
+def ellipticity(d, a, b, rho, period, c):
+    """ur/uz at the free surface, positive for retrograde motion."""
+    d, a, b, rho = map(_f64, (d, a, b, rho))
+    return lib().orc_ellipticity(_d(d), _d(a), _d(b), _d(rho), len(d), float(period), float(c))
+
+
 def dispersion(d, a, b, rho, periods, wave=0, mode=0, itype=0, dc=0.005, dt=0.025):
     d, a, b, rho, periods = map(_f64, (d, a, b, rho, periods))
-    vel = np.zeros(len(periods) * (2 if itype == 2 else 1))
+    vel = np.zeros(len(periods) * (2 if itype in (2, 3) else 1))
     ne = ctypes.c_longlong(0)
     st = lib().orc_dispersion(_d(d), _d(a), _d(b), _d(rho), len(d), _d(periods), len(periods),
                               wave, mode, itype, dc, dt, _d(vel), ctypes.byref(ne))
@@ -100,7 +118,7 @@ def forward(m, n_layers, vpvs, periods, wave=0, mode=0, itype=0, dc=0.005, dt=0.
     """forward_model(periods, model_params): returns (status, velocity[P], n_evals); itype 2:
     velocity[2P] = the phase curve, then the group curve."""
     m, periods = _f64(m), _f64(periods)
-    vel = np.zeros(len(periods) * (2 if itype == 2 else 1))
+    vel = np.zeros(len(periods) * (2 if itype in (2, 3) else 1))
     ne = ctypes.c_longlong(0)
     st = lib().orc_forward(_d(m), n_layers, vpvs, _d(periods), len(periods), wave, mode, itype,
                            dc, dt, _d(vel), ctypes.byref(ne))
@@ -111,7 +129,7 @@ def forward_batch(params, n_layers, vpvs, periods, wave=0, mode=0, itype=0, dc=0
                   nthreads=1):
     params, periods = _f64(params), _f64(periods)
     B, P = params.shape[0], len(periods)
-    vel = np.zeros((B, 2 * P if itype == 2 else P))
+    vel = np.zeros((B, 2 * P if itype in (2, 3) else P))
     status = np.zeros(B, dtype=np.int32)
     ne = ctypes.c_longlong(0)
     lib().orc_forward_batch(_d(params), B, n_layers, vpvs, _d(periods), P, wave, mode, itype, dc,
@@ -178,7 +196,7 @@ def mh_step(state, idx, cauchy, u_acc, n_layers, vpvs, periods, obs, noise_dist,
             sample_prior=False):
     periods, obs = _f64(periods), _f64(obs)
     P = len(periods)
-    assert len(obs) == (2 * P if itype == 2 else P)
+    assert len(obs) == (2 * P if itype in (2, 3) else P)
     code, na, nb = noise_arrays(noise_dist, noise_params, len(obs))
     idx = np.ascontiguousarray(idx, dtype=np.int32)
     cauchy, u_acc = _f64(cauchy), _f64(u_acc)
