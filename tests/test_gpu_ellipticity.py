@@ -181,3 +181,62 @@ def test_ellipticity_params_through_inversion(oracle, tmp_path):
     np.testing.assert_array_equal(inv.state.m.cpu().numpy(), st.m)
     np.testing.assert_allclose(inv.state.logL.cpu().numpy(), st.logL, rtol=1e-9)
     assert st.counters[:, 0].sum() > 0
+
+
+def test_joint_inversion_with_burn_in_rotation(oracle):
+    """The joint dispersion + ellipticity likelihood with covariance accumulation during burn-in
+    and rotated-frame proposals, refreshed every n_cov_chunk steps, after it
+    (src/inversion/model.py:183-193, :263-293), through Inversion.random_walk: 8 chains against a
+    host simulation that drives the oracle's step and numpy's SVD on the same cadence."""
+    from mcmc_amd.inversion import Data, EllipticityParams, Inversion
+    nl, P_, NCH = 3, 20, 8
+    n_burn, n_cov_chunk, n_mcmc = 30, 10, 90
+    bounds = {"depth": np.array([0.001, 0.15]), "vel_s": np.array([0.1, 2.0])}
+    mp = EllipticityParams(nl, bounds, {"depth": 0.05, "vel_s": 0.05}, 1.75)
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P_)).copy()
+    true_m = np.array([0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0])
+    sd = np.concatenate([np.full(P_, 0.025), np.full(P_, 0.08)])
+    rng = np.random.default_rng(12)
+    obs = oracle.forward(true_m, nl, 1.75, periods, itype=3)[1] + sd * rng.standard_normal(2 * P_)
+    noise = {"std": sd}
+    data = Data(periods, obs, "normal", noise)
+    data.model_true = true_m
+    np.random.seed(5)
+    inv = Inversion(data, mp, "normal", noise, n_burn=n_burn, n_chunk=45, n_mcmc=n_mcmc,
+                    n_cov_chunk=n_cov_chunk, n_thin=1, n_chains=NCH, n_temps=1,
+                    set_starting_model=True, out_filename=None)
+    drawn = []
+    orig = inv._draws
+
+    def record(S):
+        d = orig(S)
+        drawn.append(d)
+        return d
+    inv._draws = record
+    inv.random_walk(mp, "cauchy", rotate_params=True)
+    idx, cz, xi = (np.concatenate(x) for x in zip(*drawn))
+    assert idx.shape[0] == n_mcmc
+
+    starts = np.tile(true_m, (NCH, 1))
+    _, vel, _ = oracle.forward_batch(starts, nl, 1.75, periods, itype=3)
+    logL0 = np.array([oracle.loglik(obs, v, "normal", noise) for v in vel])
+    st = oracle.ChainState(starts, logL0, vel, 0.05, mp.assemble_param_bounds())
+    refreshed = 0
+    for s in range(n_mcmc):
+        rot = 1 | (0 if s < n_burn else 2)
+        if s >= n_burn + n_cov_chunk + 2 and s % n_cov_chunk == 0:
+            oracle.cov_accumulate(st)
+            U, sv, _ = np.linalg.svd(st.cov_sum / np.maximum(st.n_cov, 1)[:, None, None])
+            st.rot[:] = U
+            st.width[:] = np.sqrt(sv)
+            rot = 2
+            refreshed += 1
+        oracle.mh_step(st, idx[s], cz[s], xi[s], nl, 1.75, periods, obs, "normal", noise,
+                       itype=3, rotate=rot)
+    assert refreshed == 4
+    np.testing.assert_array_equal(inv.state.n_cov.cpu().numpy(), st.n_cov)
+    np.testing.assert_array_equal(inv.state.counters.cpu().numpy(), st.counters)
+    np.testing.assert_allclose(inv.state.m.cpu().numpy(), st.m, rtol=1e-8)
+    np.testing.assert_allclose(inv.state.logL.cpu().numpy(), st.logL, rtol=1e-7)
+    np.testing.assert_allclose(inv.state.cov_sum.cpu().numpy(), st.cov_sum, rtol=1e-7, atol=1e-16)
+    assert st.counters[:, 0].sum() > NCH
