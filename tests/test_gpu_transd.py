@@ -32,21 +32,25 @@ def _slots(n):
 
 
 @pytest.mark.parametrize("search", [2, 1])
-def test_forward_of_mixed_layer_counts(oracle, search):
+@pytest.mark.parametrize("wave,mode", [("rayleigh", 0), ("love", 0), ("love", 1), ("rayleigh", 2)])
+def test_forward_of_mixed_layer_counts(oracle, search, wave, mode):
+    """Models of 2..12 layers padded to 12 in one batch: Rayleigh and Love waves, fundamental and
+    higher modes."""
     import torch
     from mcmc_amd.engine import DeviceProblem
     rng = np.random.default_rng(12)
-    B = 384
+    B = 384 if mode == 0 else 192
     periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
     nb, rows, compact = _padded_models(rng, B)
-    prob = DeviceProblem(NLMAX, 1.75, periods, search=search)
+    prob = DeviceProblem(NLMAX, 1.75, periods, search=search, wave=wave, mode=mode)
     ne = torch.zeros(2, dtype=torch.int64, device=prob.device)
     vel, st = prob.forward(torch.tensor(rows, device=prob.device), n_evals=ne, n_layers_b=nb)
     vel, st = vel.cpu().numpy(), st.cpu().numpy()
     lit = 0
     n_ok = 0
     for b in range(B):
-        ost, ovel, one = oracle.forward(compact[b], int(nb[b]), 1.75, periods)
+        ost, ovel, one = oracle.forward(compact[b], int(nb[b]), 1.75, periods,
+                                        wave=int(wave == "love"), mode=mode)
         lit += one
         assert st[b] == ost, b
         if ost == 0:
@@ -54,6 +58,57 @@ def test_forward_of_mixed_layer_counts(oracle, search):
             assert np.array_equal(vel[b], ovel), b
     assert n_ok > B // 3 and int(ne[0]) == lit
     assert set(nb.tolist()) == set(range(2, NLMAX + 1))
+
+
+def test_mh_steps_of_mixed_layer_counts_love_first_overtone(oracle):
+    """Chains of 2..12 layers on Love-wave first-overtone data (curves that end at the mode's
+    cut-off period carry zeros): 40 steps against the oracle run on each compact vector."""
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    rng = np.random.default_rng(21)
+    B, S = 48, 40
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * NLMAX + [[0.1, 2.0, 1.9]] * (NLMAX + 1))
+    kind = dict(wave=1, mode=1)
+    nb_l, rows_l, comp_l = [], [], []
+    while len(rows_l) < B:
+        nb, rows, compact = _padded_models(rng, 1)
+        if oracle.forward(compact[0], int(nb[0]), 1.75, periods, **kind)[0] == 0:
+            nb_l.append(int(nb[0]))
+            rows_l.append(rows[0])
+            comp_l.append(compact[0])
+    nb, rows = np.array(nb_l, dtype=np.int32), np.array(rows_l)
+    obs = oracle.forward(comp_l[0], nb_l[0], 1.75, periods, **kind)[1] \
+        + 0.025 * rng.standard_normal(P)
+    noise = {"std": 0.025}
+    prob = DeviceProblem(NLMAX, 1.75, periods, obs, "normal", noise, bounds, wave="love", mode=1)
+    ch = DeviceChains(prob, rows, 0.05, n_layers_b=nb)
+    assert int((ch.init_likelihood() != 0).sum()) == 0
+    j = rng.integers(0, 2 ** 31, (S, B))
+    idx_c = (j % (2 * nb[None, :] + 1)).astype(np.int32)       # index into the compact vector
+    idx = np.where(idx_c < nb[None, :], idx_c, NLMAX + idx_c - nb[None, :]).astype(np.int32)
+    cz = np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5))
+    ua = rng.uniform(size=(S, B))
+    dev = prob.device
+    out = ch.steps(torch.tensor(idx, device=dev), torch.tensor(cz, device=dev),
+                   torch.tensor(ua, device=dev))
+    acc = out["accepted"].cpu().numpy()
+    m, logL = ch.m.cpu().numpy(), ch.logL.cpu().numpy()
+    n_acc = 0
+    for b in range(B):
+        n = nb_l[b]
+        sl = _slots(n)
+        v0 = oracle.forward(comp_l[b], n, 1.75, periods, **kind)[1]
+        st = oracle.ChainState(comp_l[b][None, :], [oracle.loglik(obs, v0, "normal", noise)],
+                               v0[None, :], 0.05, bounds[sl])
+        for s in range(S):
+            a, _, _ = oracle.mh_step(st, idx_c[s, b:b + 1], cz[s, b:b + 1], ua[s, b:b + 1], n,
+                                     1.75, periods, obs, "normal", noise, **kind)
+            assert a[0] == acc[s, b], (b, s)
+        np.testing.assert_array_equal(m[b, sl], st.m[0])
+        assert logL[b] == pytest.approx(st.logL[0], rel=1e-9)
+        n_acc += int(st.counters[0, 0])
+    assert n_acc > 0
 
 
 @pytest.mark.parametrize("candidates", [2, 1, 4])
