@@ -994,6 +994,68 @@ __device__ MHD_NOINLINE bool flush_deferred(int wave, EvalCount& cnt)
     return __ballot(bad) == 0ull;
 }
 
+// Periods k0..k1-1 of the fundamental mode, one after the other, by the deferring search (two
+// rounds per period); c[k0-1] (if k0 > 0) and s1st are exact inputs.  stop(k, ck), asked after
+// every period, ends the run early.  Returns the index after the last period done (all of them
+// verified: a tail that was inferred wrongly makes its period be searched again, every halving
+// evaluated), or -1 when a period has no root.
+template <class Stop>
+__device__ __forceinline__ int sequential_run(int wave, const double* t, double tscale, int k0,
+                                              int k1, double dc, double* c, int& s1st,
+                                              EvalCount& cnt, Stop stop)
+{
+    const LayerTable& T = g_T;
+    const double cc = T.cc, betmx = T.betmx, cm = T.cc;
+    const double onea = 1.5;
+    // the sequential algorithm's evaluation count before the search of the current period and of
+    // the one before (a period that is searched again must not be counted twice)
+    unsigned long long lit_cur = cnt.lit, lit_prev = cnt.lit;
+    // period k again, exactly
+    auto exact = [&](int k) -> bool {
+        double cp = (k == 0) ? cc : c[k - 1] - onea * dc;
+        if (!solve_period_wave(T, wave, t[k] / tscale, cp, (k == 0) ? cc : cm, dc, cm, betmx,
+                               k == 0, s1st, cnt))
+            return false;
+        c[k] = cp;
+        wave_sync();
+        return true;
+    };
+    int k = k0;
+    while (k < k1) {
+        const bool ifirst = (k == 0);
+        double c1 = ifirst ? cc : c[k - 1] - onea * dc;
+        lit_prev = lit_cur;
+        lit_cur = cnt.lit;
+        const int ok = solve_period_deferring(wave, t[k] / tscale, c1, ifirst ? cc : cm, dc, cm,
+                                              betmx, ifirst, s1st, cnt);
+        if (ok < 0) {
+            // the tail inferred for period k-1 was wrong: that period again, then this one from
+            // its true start (unless the run ends with the true answer)
+            cnt.lit = lit_prev;
+            lit_cur = lit_prev;
+            if (!exact(k - 1)) return -1;
+            if (stop(k - 1, c[k - 1])) return k;
+            continue;
+        }
+        if (!ok) return -1;
+        c[k] = c1;
+        wave_sync();
+        ++k;
+        if (k == k1 || stop(k - 1, c1)) {
+            if (!flush_deferred(wave, cnt)) {
+                cnt.lit = lit_cur;
+                if (!exact(k - 1)) return -1;
+                if (k < k1 && !stop(k - 1, c[k - 1])) {
+                    lit_cur = cnt.lit;
+                    continue;
+                }
+            }
+            return k;
+        }
+    }
+    return k;
+}
+
 // One phase-velocity curve (getc) for the table in T; t[] ascending periods,
 // c[] in LDS.  Wave-uniform.  Returns MHD_ST_OK or MHD_ST_NOROOT.
 // kstart > 0 resumes the fundamental mode at period kstart: c[0..kstart-1] and
@@ -1003,25 +1065,25 @@ __device__ MHD_NOINLINE int phase_curve_wave(const LayerTable& T, int wave, cons
                                        EvalCount& cnt, int kstart = 0, int s1st = 0)
 {
     if (T.b[0] <= 0.0) return MHD_ST_NOROOT;  // water layer: not part of this workload
-    const double cc = T.cc, betmx = T.betmx, cm = T.cc;
+    const double betmx = T.betmx, cm = T.cc;
     dc = fabs(dc);
-    const double one = 1.0e-2, onea = 1.5;
-    double c1 = cc, clow = cc;
-    // the sequential algorithm's evaluation count before the search of the current period and of
-    // the one before (a period that is searched again must not be counted twice)
-    unsigned long long lit_cur = cnt.lit, lit_prev = cnt.lit;
+    const double one = 1.0e-2;
     for (int k = kstart; k < P; ++k) c[k] = 0.0;
-    for (int iq = 0; iq <= mode; ++iq) {
-        for (int k = (iq == 0 ? kstart : 0); k < P; ++k) {
+    wave_sync();
+    // the fundamental mode: every period starts 1.5 dc below the answer of the one before
+    if (sequential_run(wave, t, tscale, kstart, P, dc, c, s1st, cnt,
+                       [](int, double) { return false; }) < 0)
+        return MHD_ST_NOROOT;
+    // higher modes: above the mode below, from the period before
+    for (int iq = 1; iq <= mode; ++iq) {
+        for (int k = 0; k < P; ++k) {
             const bool ifirst = (k == 0);
-            if (ifirst && iq == 0) {
-                clow = cc;
-                c1 = cc;
-            } else if (ifirst && iq > 0) {
+            double c1, clow;
+            if (ifirst) {
                 if (uni(c[0] == 0.0)) break;  // the mode below has no root at all: neither has this
                 c1 = c[0] + one * dc;
                 clow = c1;
-            } else if (!ifirst && iq > 0) {
+            } else {
                 // c[k] is still the mode below: past its cut-off this mode has none either
                 // (cut-off periods shrink with the mode number), and a search from c = 0 upward
                 // would run through wavenumbers where the secular function is rounding noise
@@ -1032,47 +1094,13 @@ __device__ MHD_NOINLINE int phase_curve_wave(const LayerTable& T, int wave, cons
                 clow = c[k] + one * dc;
                 c1 = c[k - 1];
                 if (c1 < clow) c1 = clow;
-            } else {
-                clow = cm;
-                c1 = c[k - 1] - onea * dc;
             }
-            // the fundamental mode is searched with deferred tails (two rounds per period)
-            const bool defer = (iq == 0);
-            lit_prev = lit_cur;
-            lit_cur = cnt.lit;
-            const int ok = defer ? solve_period_deferring(wave, t[k] / tscale, c1, clow, dc, cm, betmx,
-                                                          ifirst, s1st, cnt)
-                                 : (int)solve_period_wave(T, wave, t[k] / tscale, c1, clow, dc, cm,
-                                                          betmx, ifirst, s1st, cnt);
-            if (ok < 0) {
-                // the tail inferred for period k-1 was wrong: that period again, every halving
-                // evaluated, then this one from its true start
-                const int kp = k - 1;
-                cnt.lit = lit_prev;
-                lit_cur = lit_prev;
-                double cp = (kp == 0) ? cc : c[kp - 1] - onea * dc;
-                if (!solve_period_wave(T, wave, t[kp] / tscale, cp, (kp == 0) ? cc : cm, dc, cm,
-                                       betmx, kp == 0, s1st, cnt))
-                    return MHD_ST_NOROOT;
-                c[kp] = cp;
-                --k;
-                continue;
-            }
-            if (!ok) {
-                if (iq == 0) return MHD_ST_NOROOT;
+            if (!solve_period_wave(T, wave, t[k] / tscale, c1, clow, dc, cm, betmx, ifirst, s1st,
+                                   cnt)) {
                 for (int i = k; i < P; ++i) c[i] = 0.0;
                 break;
             }
             c[k] = c1;
-            if (defer && k == P - 1 && !flush_deferred(wave, cnt)) {
-                // the last period's tail: the same repair
-                cnt.lit = lit_cur;
-                double cp = (k == 0) ? cc : c[k - 1] - onea * dc;
-                if (!solve_period_wave(T, wave, t[k] / tscale, cp, (k == 0) ? cc : cm, dc, cm,
-                                       betmx, k == 0, s1st, cnt))
-                    return MHD_ST_NOROOT;
-                c[k] = cp;
-            }
         }
     }
     return MHD_ST_OK;

@@ -1220,21 +1220,21 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             // next periods are searched sequentially while that lasts, and once an answer is the
             // predicted root again the predictions for the later periods stand.
             {
+                // (two rounds per period: the deferring search, every tail verified on return)
+                const int klast = kstart + RESYNC_PERIODS < nP ? kstart + RESYNC_PERIODS : nP;
+                auto back = [&](int k, double ck) -> bool {
+                    return uni(fabs(ck - uniform_value(S.lo[k])) <= 2.0e-6 * ck);
+                };
+                const int kdone = sequential_run(wave, t, tscale, kstart, klast, dc, c, s1st, cnt, back);
+                PROF_ADD(4)
+                if (kdone < 0) return MHD_ST_NOROOT;
                 bool resynced = false;
-                for (int tries = 0; tries < RESYNC_PERIODS && kstart < nP && !resynced; ++tries) {
-                    const int k = kstart;
-                    double ck = uniform_value(c[k - 1]) - 1.5 * dc;
-                    const bool ok2 = solve_period_wave(T, wave, t[k] / tscale, ck, cm, dc, cm, betmx,
-                                                       false, s1st, cnt);
-                    PROF_ADD(4)
-                    if (!ok2) return MHD_ST_NOROOT;
-                    c[k] = ck;
-                    wave_sync();
-                    kstart = k + 1;
-                    if (kstart >= P) return MHD_ST_OK;
-                    resynced = uni(fabs(ck - uniform_value(S.lo[k])) <= 2.0e-6 * ck);
-                    cr = ck;
+                if (kdone > kstart) {
+                    cr = uniform_value(c[kdone - 1]);
+                    resynced = back(kdone - 1, cr);
                 }
+                kstart = kdone;
+                if (kstart >= P) return MHD_ST_OK;
                 if (resynced && kstart < nP) {
                     CHAIN_EVENT(26)
                     break;
