@@ -4,6 +4,9 @@ run() { timeout -k 10 300 python bench.py --no-cpu --steps 1000 --warmup 200 "$@
 run
 run --rotation on
 run --itype group
+run --itype phase+group
+run --itype phase+ellipticity
+run --itype phase+ellipticity --rotation on
 run --wave love
 run --layers 12
 run --layers 3
