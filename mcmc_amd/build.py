@@ -13,18 +13,33 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 
-def build(force=False, verbose=False):
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not force and os.path.exists(OUT) and all(
-            os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
-        return OUT
-    cmd = [HIPCC] + FLAGS + ["-o", OUT, SRC]
+# A test build: every third interpolated root of the deferring period search is replaced by a
+# wrong one, so that the later verification of the inferred halvings fails and the periods are
+# searched again.  Results must be those of the product build (tests/test_gpu_deferred_tails.py).
+OUT_SABOTAGE = os.path.join(HERE, "lib", "libmcmc_amd_sabotage.so")
+
+
+def _compile(out, extra, force, verbose):
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not force and os.path.exists(out) and all(
+            os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
+        return out
+    cmd = [HIPCC] + FLAGS + extra + ["-o", out, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
+
+
+def build(force=False, verbose=False):
+    return _compile(OUT, [], force, verbose)
+
+
+def build_test_variants(force=False, verbose=False):
+    return _compile(OUT_SABOTAGE, ["-DMHD_DEFER_SABOTAGE"], force, verbose)
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_test_variants(force="--force" in sys.argv, verbose=True)
     print(OUT)

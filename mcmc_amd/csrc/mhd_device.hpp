@@ -902,6 +902,11 @@ __device__ __forceinline__ int solve_period_impl(int wave, double t1, double& c1
                              c2 * (g0 * g1) / ((g2 - g0) * (g2 - g1));
             if (uni(q > fmin(c1, c2) && q < fmax(c1, c2))) root = q;
         }
+#ifdef MHD_DEFER_SABOTAGE
+        // test build: every third inference starts from a wrong root, so that the verification of
+        // the tails and the searches it sends back are exercised (the results must not change)
+        if ((cnt.lit % 3ull) == 0ull) root = c1 + 0.37 * (c2 - c1);
+#endif
         const bool below1 = uni(c1 <= root);
         double d1 = c1, d2 = c2, d3 = c3, px = 0.0;
         int ds1 = s1, n = 0, dctrl = nctrl, pw = 0;

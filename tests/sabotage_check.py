@@ -1,0 +1,84 @@
+"""Run by tests/test_gpu_deferred_tails.py in a process of its own, with MCMC_AMD_LIB naming the
+test build of the library in which every third interpolated root of the deferring period search
+is wrong: the verification of the inferred halvings must catch each of them and the periods be
+searched again, so curves, evaluation counts, decisions and states are still the oracle's."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def lvz_models(rng, B, nl):
+    """Prior draws with unsorted velocities: low-velocity zones, curves that change branches."""
+    d = np.sort(rng.uniform(0.001, 0.15, (B, nl)), axis=1)
+    v = rng.uniform(0.1, 2.0, (B, nl + 1))
+    return np.concatenate([d, v], axis=1)
+
+
+def main():
+    import torch
+    import oracle
+    from mcmc_amd import _lib as L
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    assert L.LIB_PATH.endswith("libmcmc_amd_sabotage.so"), L.LIB_PATH
+    rng = np.random.default_rng(77)
+    nl, P, B = 6, 40, 256
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    params = lvz_models(rng, B, nl)
+    ost, ovel, olit = oracle.forward_batch(params, nl, 1.75, periods, nthreads=8)
+    execs = {}
+    for search in (1, 2):
+        prob = DeviceProblem(nl, 1.75, periods, search=search)
+        ne = torch.zeros(2, dtype=torch.int64, device=prob.device)
+        vel, st = prob.forward(torch.tensor(params, device=prob.device), n_evals=ne)
+        vel, st = vel.cpu().numpy(), st.cpu().numpy()
+        ok = ost == 0
+        assert (st == ost).all() and ok.sum() > B // 2
+        assert np.array_equal(vel[ok], ovel[ok])
+        assert int(ne[0]) == olit, (search, int(ne[0]), olit)
+        execs[search] = int(ne[1])
+    # the sabotage is at work: the product build executes ~7.6 evaluations per sequential one
+    assert execs[1] > 9.0 * olit, (execs, olit)
+
+    # MH steps with the wave-sequential and the predicted search
+    bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
+    good = params[ost == 0][:64]
+    Bc, S = len(good), 40
+    obs = ovel[ost == 0][0] + 0.025 * rng.standard_normal(P)
+    noise = {"std": 0.025}
+    idx = rng.integers(0, 2 * nl + 1, (S, Bc)).astype(np.int32)
+    cz = np.tan(np.pi * (rng.uniform(size=(S, Bc)) - 0.5))
+    ua = rng.uniform(size=(S, Bc))
+    _, v0, _ = oracle.forward_batch(good, nl, 1.75, periods, nthreads=8)
+    logL0 = np.array([oracle.loglik(obs, v, "normal", noise) for v in v0])
+    state = oracle.ChainState(good, logL0, v0, 0.05, bounds)
+    acc = np.zeros((S, Bc), dtype=np.uint8)
+    lit = 0
+    oracle.set_threads(8)
+    for s in range(S):
+        acc[s], _, n = oracle.mh_step(state, idx[s], cz[s], ua[s], nl, 1.75, periods, obs,
+                                      "normal", noise)
+        lit += n
+    oracle.set_threads(1)
+    for search, candidates in ((1, 1), (2, 2), (2, 4)):
+        prob = DeviceProblem(nl, 1.75, periods, obs, "normal", noise, bounds, search=search,
+                             candidates=candidates)
+        ch = DeviceChains(prob, good, 0.05)
+        assert int((ch.init_likelihood() != 0).sum()) == 0
+        ch.n_evals.zero_()
+        dev = prob.device
+        out = ch.steps(torch.tensor(idx, device=dev), torch.tensor(cz, device=dev),
+                       torch.tensor(ua, device=dev))
+        assert (out["accepted"].cpu().numpy() == acc).all(), (search, candidates)
+        assert np.array_equal(ch.m.cpu().numpy(), state.m)
+        assert np.array_equal(ch.pred.cpu().numpy(), state.pred)
+        np.testing.assert_allclose(ch.logL.cpu().numpy(), state.logL, rtol=1e-9)
+        assert int(ch.n_evals[0]) == lit, (search, candidates, int(ch.n_evals[0]), lit)
+    print("sabotage check ok: executed / sequential evaluations %.1f (sequential search), %.1f "
+          "(predicted)" % (execs[1] / olit, execs[2] / olit))
+
+
+if __name__ == "__main__":
+    main()
