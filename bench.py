@@ -140,6 +140,11 @@ def main():
         if args.chains % args.temps:
             raise SystemExit("--chains must be a multiple of --temps")
 
+    if os.environ.get("MCMC_AMD_BENCH_WATCHDOG"):
+        # debugging aid: after that many seconds every thread's stack goes to stderr and the
+        # process ends (a hung collective otherwise says nothing)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MCMC_AMD_BENCH_WATCHDOG"]), exit=True)
     import torch
     import torch.distributed as dist
     from mcmc_amd.engine import DeviceChains, DeviceProblem
@@ -152,9 +157,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # (a rehearsal of the multi-process path on a box with fewer GPUs than ranks: the ranks share
+    # the GPUs there are, and MCMC_AMD_DIST_BACKEND=gloo stands in for RCCL, which refuses two
+    # ranks on one device; on a node with one GPU per rank neither changes anything)
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        backend = os.environ.get("MCMC_AMD_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     nl = args.layers
     periods, bounds = problem_inputs(nl)
@@ -209,6 +222,8 @@ def main():
             if args.tempering:
                 full = chains.logL
                 if world > 1:
+                    if dist.get_backend() != "nccl":
+                        torch.cuda.synchronize()  # (the gloo stand-in copies through the host)
                     dist.all_gather_into_tensor(logL_all, chains.logL)
                     full = logL_all
                 tempering_sweep(full, beta_all, u_swap[a // args.thin], args.temps,
