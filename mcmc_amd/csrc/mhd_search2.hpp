@@ -79,7 +79,7 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
 
 // half-width, in abscissae, of the first window of a round that the hint places
 #ifndef SHAPED_BASE_M
-#define SHAPED_BASE_M 2
+#define SHAPED_BASE_M 1
 #endif
 
 // hint steps (in dc) from which predict_coarse spaces the abscissae of a window 2 and 4 dc apart
@@ -97,7 +97,7 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
 #define HINT_STRETCH 0.0
 #endif
 #ifndef HINT_TREND_SLACK
-#define HINT_TREND_SLACK 1.0
+#define HINT_TREND_SLACK 1.5
 #endif
 
 // share of the last period-to-period change of (root - hint) that predict_coarse carries on
