@@ -163,3 +163,26 @@ def test_inversion_tempering_and_rotation_run(oracle, tmp_path):
     assert f["model_params"].shape[0] == 10 and f["model_params"].shape[2] == 7
     chains = inv.chains
     assert len(chains) == 8 and chains[0].data_pred.shape == (P,)
+
+
+def test_the_binding_shown_to_maintainers_works(oracle):
+    """The ctypes stub printed in INTEGRATION.md (the reference-side binding a maintainer would
+    add) is executed as it stands, only the library's path made absolute."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    start = text.index("# src/inversion/_mhd.py")
+    code = text[start:text.index("```", start)]
+    code = code.replace('"mcmc_amd/lib/libmcmc_amd.so"',
+                        repr(os.path.join(root, "mcmc_amd", "lib", "libmcmc_amd.so")))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    nl = 3
+    periods = np.flip(1 / np.logspace(0.3, 1.3, 20)).copy()
+    rng = np.random.default_rng(3)
+    params = np.concatenate([np.sort(rng.uniform(0.001, 0.15, (16, nl)), axis=1),
+                             np.sort(rng.uniform(0.1, 2.0, (16, nl + 1)), axis=1)], axis=1)
+    vel, st = ns["forward_batch"](params, nl, 1.75, periods)
+    ost, ovel, _ = oracle.forward_batch(params, nl, 1.75, periods)
+    assert (st == ost).all() and (ost == 0).any()
+    assert np.array_equal(vel[ost == 0], ovel[ost == 0])
