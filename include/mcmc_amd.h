@@ -135,7 +135,7 @@ typedef struct mhd_problem {
 typedef struct mhd_chains {
     double *m;           /* device [B,NP] model_params.model_params           */
     double *logL;        /* device [B]                                        */
-    double *pred;        /* device [B,P] data_pred                            */
+    double *pred;        /* device [B,ND] data_pred (ND: see n_periods)        */
     double *params_prev; /* device [B,NP] normalised previous accepted params */
     double *width;       /* device [B,NP] proposal_width                      */
     double *rot;         /* device [B,NP,NP] rotation_matrix, or NULL         */
@@ -195,20 +195,20 @@ int mhd_secular_batch(const mhd_problem_t *prob, const double *params /* device 
 /*
  * DispersionCurveParams.forward_model for B parameter vectors
  * (src/inversion/model_params.py:178-209; the disba call at :201-206).
- * vel[b,:] is the phase (or group) velocity curve, status[b] is MHD_ST_OK or
+ * vel[b,:] is the datum prob->itype names (a curve of P values, or two in a row), status[b] is MHD_ST_OK or
  * the code of the exception the reference would raise.  n_evals, if not NULL,
  * is device uint64[2] and is INCREMENTED by {secular evaluations the
  * sequential disba algorithm performs, evaluations actually executed}.
  */
 int mhd_forward_batch(const mhd_problem_t *prob, const double *params /* device [B,NP] */,
-                      int32_t B, double *vel /* device [B,P] */,
+                      int32_t B, double *vel /* device [B,ND] */,
                       int32_t *status /* device [B] */, uint64_t *n_evals, void *stream);
 
 /*
  * Model.get_likelihood for B predicted curves (src/inversion/model.py:420-447);
  * sums in numpy's float64 add.reduce order.
  */
-int mhd_loglik_batch(const mhd_problem_t *prob, const double *pred /* device [B,P] */,
+int mhd_loglik_batch(const mhd_problem_t *prob, const double *pred /* device [B,ND] */,
                      int32_t B, double *logL /* device [B] */, void *stream);
 
 /*
@@ -225,7 +225,7 @@ int mhd_loglik_batch(const mhd_problem_t *prob, const double *pred /* device [B,
  * rotate is a mask of MHD_ROT_*.  sample_prior != 0 skips the forward model
  * and uses logL_new = 1 (model.py:234-236).
  * Optional outputs (NULL to skip): accepted[S,B] (uint8), status[S,B],
- * hist_m[S/hist_every,B,NP], hist_logL[S/hist_every,B], hist_pred[S/hist_every,B,P]
+ * hist_m[S/hist_every,B,NP], hist_logL[S/hist_every,B], hist_pred[S/hist_every,B,ND]
  * written after every hist_every-th step (the per-step records of
  * Inversion.store_samples, src/inversion/inversion.py:431-457).  n_evals as in
  * mhd_forward_batch.
