@@ -330,9 +330,7 @@ class Inversion:
             raise NotImplementedError("only the 'cauchy' proposal is mirrored")
         if self.tempering:
             return self._random_walk_tempered(rotate_params, sample_prior)
-        rec = {}
-        step = 0
-        while step < self.n_mcmc:
+        def segment(step):
             # a segment ends at a chunk boundary and before a step on which the rotation matrix
             # is refreshed
             seg = min(self.n_chunk - step % self.n_chunk, self.n_mcmc - step)
@@ -342,15 +340,26 @@ class Inversion:
                     seg = nxt - step
                 if step < self.n_burn:
                     seg = min(seg, self.n_burn - step)
-            idx, cz, xi = self._draws(seg * self.n_thin)
-            outs = self._run_segment(step, seg, idx, cz, xi, rotate_params, sample_prior)
+            return seg
+
+        rec = {}
+        step = 0
+        seg = segment(0) if self.n_mcmc > 0 else 0
+        draws = self._draws(seg * self.n_thin) if seg else None
+        while step < self.n_mcmc:
+            outs = self._run_segment(step, seg, *draws, rotate_params, sample_prior)
             self._store(rec, outs)
             step += seg
             self._n_step = step
+            # the draws of the next segment (the same sequence of np.random calls as ever) while
+            # the device works on this one: the launches above do not wait for it
+            seg_next = segment(step) if step < self.n_mcmc else 0
+            draws = self._draws(seg_next * self.n_thin) if seg_next else None
             if step % self.n_chunk == 0 or step == self.n_mcmc:
                 if self.out_filename is not None:
                     self._write_chunk((step - 1) // self.n_chunk, self._finish(rec))
                 rec = {}
+            seg = seg_next
         self._sync_host()
 
     def _random_walk_tempered(self, rotate_params, sample_prior):
