@@ -240,3 +240,35 @@ def test_joint_inversion_with_burn_in_rotation(oracle):
     np.testing.assert_allclose(inv.state.logL.cpu().numpy(), st.logL, rtol=1e-7)
     np.testing.assert_allclose(inv.state.cov_sum.cpu().numpy(), st.cov_sum, rtol=1e-7, atol=1e-16)
     assert st.counters[:, 0].sum() > NCH
+
+
+def test_forward_ellipticity_of_mixed_layer_counts(oracle):
+    """The joint datum for models of 2..12 layers padded to 12 in one batch."""
+    import torch
+    from mcmc_amd.engine import DeviceProblem
+    rng = np.random.default_rng(44)
+    NLMAX, B = 12, 192
+    NPmax = 2 * NLMAX + 1
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    nb = rng.integers(2, NLMAX + 1, B).astype(np.int32)
+    rows = np.full((B, NPmax), 0.777)
+    compact = []
+    for b in range(B):
+        n = int(nb[b])
+        d = np.sort(rng.uniform(0.001, 0.15, n))
+        v = np.sort(rng.uniform(0.1, 2.0, n + 1))
+        rows[b, :n] = d
+        rows[b, NLMAX:NLMAX + n + 1] = v
+        compact.append(np.concatenate([d, v]))
+    prob = DeviceProblem(NLMAX, 1.75, periods, itype="phase+ellipticity")
+    vel, st = prob.forward(torch.tensor(rows, device=prob.device), n_layers_b=nb)
+    vel, st = vel.cpu().numpy(), st.cpu().numpy()
+    n_ok = 0
+    for b in range(B):
+        ost, ovel, _ = oracle.forward(compact[b], int(nb[b]), 1.75, periods, itype=3)
+        assert st[b] == ost, b
+        if ost == 0:
+            n_ok += 1
+            assert np.array_equal(vel[b, :P], ovel[:P]), b
+            np.testing.assert_allclose(vel[b, P:], ovel[P:], rtol=1e-8, atol=1e-12)
+    assert n_ok > B // 2
