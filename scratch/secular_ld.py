@@ -7,7 +7,8 @@ import oracle
 LD = np.longdouble
 
 
-def secular_ld(d, a, b, rho, period, c):
+def compound_ld(d, a, b, rho, period, c):
+    """All five components of the compound vector at the surface."""
     d, a, b, rho = (np.asarray(x, dtype=LD) for x in (d, a, b, rho))
     omega = LD(2) * LD(np.pi) / LD(period)
     omega = 2 * np.arctan2(LD(0), LD(-1)) / LD(period)          # pi in extended precision
@@ -63,7 +64,11 @@ def secular_ld(d, a, b, rho, period, c):
         ca[2, 3] = tt * ca[1, 2]; ca[2, 4] = tt * ca[0, 2]
         ee = e @ ca
         e = ee / np.abs(ee).max()
-    return e[0]
+    return e
+
+
+def secular_ld(d, a, b, rho, period, c):
+    return compound_ld(d, a, b, rho, period, c)[0]
 
 
 if __name__ == "__main__":
