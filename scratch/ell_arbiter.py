@@ -55,3 +55,20 @@ print("compound vector (long double):", [float(x) for x in ev])
 print("ellipticity long double: -k e2/e1 = %.15g, e3/(k e2) = %.15g" % (float(-k * ev[2] / ev[1]), float(ev[3] / (k * ev[2]))))
 kd = 2 * np.pi / T / c
 print("ellipticity double (oracle): -k e2/e1 = %.15g, e3/(k e2) = %.15g" % (-kd * e[2] / e[1], e[3] / (kd * e[2])))
+
+# the root itself (extended precision, bisection around the answer) and the ellipticity there
+f = lambda x: float(SL.compound_ld(*lt, T, x)[0])
+lo, hi = c * (1 - 3e-6), c * (1 + 3e-6)
+assert f(lo) * f(hi) < 0
+for _ in range(80):
+    mid = 0.5 * (lo + hi)
+    if f(mid) * f(lo) > 0: lo = mid
+    else: hi = mid
+root = 0.5 * (lo + hi)
+ev = SL.compound_ld(*lt, T, root)
+k = omega / LD(root)
+print("root %.15g (answer %.15g, %.2e relative away); there e0 = %.2e and the two ratios are %.12g and %.12g" %
+      (root, c, c / root - 1, float(ev[0]), float(-k * ev[2] / ev[1]), float(ev[3] / (k * ev[2]))))
+for x in (c * (1 - 1e-6), c * (1 - 3e-7), c, c * (1 + 3e-7), c * (1 + 1e-6)):
+    ev = SL.compound_ld(*lt, T, x); k = omega / LD(x)
+    print("  c %.12f: e0 %+.3e  -k e2/e1 %.6f  e3/(k e2) %.6f" % (x, float(ev[0]), float(-k * ev[2] / ev[1]), float(ev[3] / (k * ev[2]))))
