@@ -80,7 +80,10 @@ __global__ __launch_bounds__(64) MHD_REGS void secular_kernel(mhd_problem_t p, c
 {
     // one wave per query keeps the table code identical to the other kernels
     LayerTable& T = g_T;
-    if ((threadIdx.x & 63) == 0) g_PS.prof_slot = (int)blockIdx.x;
+    if ((threadIdx.x & 63) == 0) {
+        g_PS.prof_slot = (int)blockIdx.x;
+        g_PS.abort = 0;
+    }
     __shared__ double m[MAXNP];
     const int q = blockIdx.x;
     if (q >= N) return;
@@ -100,7 +103,10 @@ __global__ __launch_bounds__(64) MHD_REGS void forward_kernel(mhd_problem_t p, c
                                                      unsigned long long* n_evals, int search)
 {
     LayerTable& T = g_T;
-    if ((threadIdx.x & 63) == 0) g_PS.prof_slot = (int)blockIdx.x;
+    if ((threadIdx.x & 63) == 0) {
+        g_PS.prof_slot = (int)blockIdx.x;
+        g_PS.abort = 0;
+    }
     __shared__ double m[MAXNP];
     __shared__ double t[MAXP];
     __shared__ double out[MAXP];
@@ -306,7 +312,10 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     unsigned long long* n_evals, int search)
 {
     LayerTable& T = g_T;
-    if ((threadIdx.x & 63) == 0) g_PS.prof_slot = (int)blockIdx.x;
+    if ((threadIdx.x & 63) == 0) {
+        g_PS.prof_slot = (int)blockIdx.x;
+        g_PS.abort = 0;
+    }
     __shared__ double m[MAXNP];     // current parameters
     __shared__ double mn[MAXNP];    // normalised current parameters
     __shared__ double test[MAXNP];  // proposal
@@ -648,6 +657,9 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
 // NW = 4 kernel the n4 most expensive chains, the NW = 2 kernel all others -- the 2 * n4
 // cheapest ones two to a workgroup, each with ONE wave and one candidate ("split" workgroups,
 // whose two waves never meet in a barrier).
+#ifndef ABORT_MOOT
+#define ABORT_MOOT 1
+#endif
 template <int NW>
 __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     mhd_problem_t p, mhd_chains_t ch, int B, int S, const int32_t* idx, const double* cauchy,
@@ -714,7 +726,10 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     const int nlmax = p.n_layers, NP = 2 * nlmax + 1, P = p.n_periods, ND = data_length(p);
     const int nl = layers_of(p, ib);
     LayerTable& T = g_T;
-    if (lane == 0) g_PS.prof_slot = ib;
+    if (lane == 0) {
+        g_PS.prof_slot = ib;
+        g_PS.abort = 0;
+    }
 
     if (threadIdx.x < NP) {
         lo[threadIdx.x] = p.bounds[3 * threadIdx.x];
@@ -822,16 +837,20 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         if ((rotate & MHD_ROT_ACCUMULATE) && writer)
             cov_accumulate_wave(ch, ib, NP, mn, tmp[w0], lane);
     };
-    // accept test of the candidate of wave c (model.py:449-467) and, if it passes, the move
+    // accept test (model.py:449-467) of a candidate for step j with likelihood lnew
+    auto accept_test = [&](double lnew, int j) -> int {
+        double dl = lnew - logL;
+        dl = dl / Temp;
+        if (ch.beta) dl = beta * dl;
+        return __builtin_amdgcn_readfirstlane((int)(u_acc[(size_t)j * B + ib] <= exp(dl)));
+    };
+    // the candidate of wave c settles step j: the accept test and, if it passes, the move
     auto settle = [&](int c, int j) -> int {
         const int st = r_st[c];
         int acc = 0;
         if (st == MHD_ST_OK) {
             const double lnew = r_logL[c];
-            double dl = lnew - logL;
-            dl = dl / Temp;
-            if (ch.beta) dl = beta * dl;
-            acc = __builtin_amdgcn_readfirstlane((int)(u_acc[(size_t)j * B + ib] <= exp(dl)));
+            acc = accept_test(lnew, j);
             if (acc) {
                 if (writer) {
                     if (lane < NP) {
@@ -889,15 +908,16 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         int st = MHD_ST_BOUNDS, trouble = 0;
         double lnew = 0.0;
         EvalCount cnt = {0, 0};
+        if (lane == 0) g_PS.abort = 0;
         if (jc < S) {
             build_layer_table(T, test[w], nl, p.vpvs, lane, nlmax);
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
                                        scratch[w], cnt, policy.stepwise(), pred, ghint,
                                        !hinted ? 0 : (fabs(czc) <= hlim[kkc] ? 2 : 1));
-                trouble = __builtin_amdgcn_readfirstlane(g_PS.trouble);
+                trouble = st == MHD_ST_ABORTED ? 0 : __builtin_amdgcn_readfirstlane(g_PS.trouble);
                 // (the waves of a chain update the limits unordered; they are heuristics)
-                if (lane == 0)
+                if (lane == 0 && st != MHD_ST_ABORTED)
                     hint_limit_update(hlim, kkc, czc, __builtin_amdgcn_readfirstlane(g_PS.hinted));
             } else {
                 st = forward_wave(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
@@ -906,6 +926,11 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             wave_sync();
             if (st == MHD_ST_OK) lnew = loglik_wave(p, newpred[w], scratch[w] + 2 * MAXP, lane);
             exec += cnt.exec;
+            // A candidate that passes its accept test ends the round's steps wherever it is
+            // reached, and if it is not reached an earlier one did: either way the candidates
+            // after it are not needed, and their waves are told to give their curves up.
+            if (ABORT_MOOT && st == MHD_ST_OK && w + 1 < w0 + nw && accept_test(lnew, jc) && lane == 0)
+                for (int c = w + 1; c < w0 + nw; ++c) g_PS_OF(c).abort = 1;
         }
         if (lane == 0) {
             r_step[w] = jc;
@@ -939,6 +964,9 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
                 book(s, MHD_ST_BOUNDS, 0);
             }
             if (j >= S) break;
+            // (a curve that was given up is never reached: a candidate before it was accepted.
+            // Should it be, the step is simply run again in the next round.)
+            if (r_st[c] == MHD_ST_ABORTED) break;
             begin_step();
             lit += r_lit[c];
             s = j + 1;

@@ -59,6 +59,8 @@ struct PredictScratch {
     int trouble;  // repairs the last predicted curve needed (9: the predictor gave up)
     int hinted;   // predict_hint for the last curve: 0 not tried, 1 settled, 2 gave up
     int prof_slot;  // where a profiling build books this wave's cycles (the chain's index)
+    int abort;      // set by another wave of the workgroup: the curve this wave works on is no
+                    // longer needed (see abort_requested)
 };
 
 static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
@@ -66,6 +68,20 @@ static_assert(WAVE_LDS_SEARCH_OFFSET + sizeof(PredictScratch) <= WAVE_LDS_BYTES,
 #define g_PS                                                                              \
     (*reinterpret_cast<PredictScratch*>(mhd_wave_lds + (threadIdx.x >> 6) * WAVE_LDS_BYTES + \
                                         WAVE_LDS_SEARCH_OFFSET))
+// the same block of wave w of this workgroup
+#define g_PS_OF(w)                                                                         \
+    (*reinterpret_cast<PredictScratch*>(mhd_wave_lds + (w) * WAVE_LDS_BYTES + WAVE_LDS_SEARCH_OFFSET))
+
+// A predicted curve can be given up between two rounds of evaluations: the Metropolis-Hastings
+// kernels run several candidates of a chain at once, and once one of them is accepted the later
+// ones started from a state the chain never has.  The wave that finds its candidate acceptable
+// sets `abort` of the waves after it; they look at it once per round and return
+// MHD_ST_ABORTED.  A request only ever saves time: a curve that is returned is complete.
+constexpr int MHD_ST_ABORTED = -1;  // internal: never leaves a kernel
+__device__ __forceinline__ bool abort_requested()
+{
+    return __builtin_amdgcn_readfirstlane(*(volatile int*)&g_PS.abort) != 0;
+}
 
 // A secant iterate x(n+1) is within about C |x(n+1)-x(n)| |x(n+1)-x(n-1)| of the root; with this
 // bound on the product it is taken as the root without being evaluated (C, the curvature over
@@ -171,7 +187,7 @@ __device__ __forceinline__ int predict_coarse(int wave, const double* t, int kbe
 #endif
 
     while (k0 < P) {
-        if (++rounds > 96) return -1;
+        if (++rounds > 96 || abort_requested()) return -1;
         // ---- the windows of this round: period k0+q gets the lanes woff[q]..woff[q+1]-1 and
         // the abscissae wbase[q] + j*dc
         int nq = 0, g = 1;
@@ -359,7 +375,7 @@ __device__ __forceinline__ int predict_coarse(int wave, const double* t, int kbe
                     }
                     if (resolved > 0) break;
                     // its own round: 64 abscissae downwards from the start
-                    if (++rounds > 96) return -1;
+                    if (++rounds > 96 || abort_requested()) return -1;
                     const double xd = st - lane * dc;
                     const bool act = xd > cc;
                     SecVal vd = {0.0, 0};
@@ -616,7 +632,7 @@ __device__ __forceinline__ void predict_refine(int wave, const double* t, int kb
                 }
             }
             const unsigned long long todo = __ballot(!done);
-            if (todo == 0ull) break;
+            if (todo == 0ull || abort_requested()) break;
             cnt.exec += (unsigned long long)__popcll(todo);
             if (!done) {
                 const SecVal v = eval_secular(wave, omega, x);
@@ -731,6 +747,7 @@ __device__ __forceinline__ int predict_hint(int wave, const double* t, int P, do
             }
             const unsigned long long nfail = __ballot(failed);
             const unsigned long long todo = __ballot(!done);
+            if (it >= 2 && abort_requested()) return -1;
             if (nfail != 0ull) {
                 HINT_WHY(16)
 #ifdef MHD_PROFILE
@@ -1011,7 +1028,8 @@ __device__ __forceinline__ int period_of_abscissa(int i, int kstart, int kend)
 // ---- stage 4 ----------------------------------------------------------------
 // Really evaluates abscissae vbeg..npts-1 of the replay pass over periods kstart..kend-1 and
 // returns the first whose sign is not the inferred one (or whose value is not the answer the
-// replay gave for its period), npts if there is none.  Out of line, with the pair evaluation
+// replay gave for its period), npts if there is none, -1 if the curve was given up (see
+// abort_requested).  Out of line, with the pair evaluation
 // inlined: its registers are saved once per pass, not once per round.
 __device__ MHD_NOINLINE int verify_pass(int wave, const double* t, double tscale, double dc,
                                         const double* c, int kstart, int kend, int kfail,
@@ -1024,6 +1042,10 @@ __device__ MHD_NOINLINE int verify_pass(int wave, const double* t, double tscale
     int first_bad = npts;
 #if !VERIFY_PAIRS
             for (int base = vbeg; base < npts; base += 64) {
+                if (abort_requested()) {
+                    first_bad = -1;
+                    break;
+                }
                 const int i = base + lane;
                 const bool act = i < npts;
                 bool bad = false;
@@ -1048,6 +1070,10 @@ __device__ MHD_NOINLINE int verify_pass(int wave, const double* t, double tscale
 #else
             // two abscissae per lane, neighbours of one period's search as a rule
             for (int base = vbeg; base < npts; base += 128) {
+                if (abort_requested()) {
+                    first_bad = -1;
+                    break;
+                }
                 const int i0 = base + 2 * lane, i1 = i0 + 1;
                 const bool act0 = i0 < npts, act1 = i1 < npts;
                 bool bad0 = false, bad1 = false;
@@ -1116,10 +1142,12 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
         if (lane == 0) { atomicAdd(&g_prof[11], 1ull); atomicAdd(&g_prof[12], (unsigned long long)(nP < 0)); }
 #endif
     }
+    if (abort_requested()) return MHD_ST_ABORTED;
     if (nP < 0) {
         nP = stepwise ? predict_stepwise(wave, t, 0, P, tscale, dc, 0.0, 0, stepwise, cnt)
                       : predict_coarse(wave, t, 0, P, tscale, dc, 0.0, 0, hint, use_hint != 0, cnt);
         PROF_ADD(0)
+        if (abort_requested()) return MHD_ST_ABORTED;
         if (nP < 0) {
             S.trouble = 9;
             const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt);
@@ -1134,6 +1162,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
     const double cc = T.cc, betmx = T.betmx, cm = T.cc;
     int s1st = 0, kstart = 0, repairs = 0;
     for (;;) {
+        if (abort_requested()) return MHD_ST_ABORTED;
         // replay periods kstart..kend-1 (c[kstart-1] and s1st are exact); period kplain, if
         // any, is not a plain case and ends the pass
         const ReplayPass rp = replay_pass(kstart, nP, c, cc, dc, betmx + dc, betmx, s1st);
@@ -1150,6 +1179,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             const int first_bad = verify_pass(wave, t, tscale, dc, c, kstart, kend, kfail, vbeg,
                                               npts, cnt);
             PROF_ADD(3)
+            if (first_bad < 0) return MHD_ST_ABORTED;
             if (first_bad == npts) break;
             // periods before the first wrong sign are exact
             const int kbad = period_of(first_bad);
@@ -1178,6 +1208,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
                                               cm, betmx, ifirst, s1st, cnt);
             PROF_ADD(4)
             if (!ok) return MHD_ST_NOROOT;
+            if (abort_requested()) return MHD_ST_ABORTED;
 #ifdef MHD_PROFILE
             {
                 // where the sequential search ended against the predicted root, and where in the
@@ -1247,6 +1278,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
                           : predict_coarse(wave, t, kstart, P, tscale, dc, cr, s1st, hint,
                                            use_hint != 0, cnt);
             PROF_ADD(0)
+            if (abort_requested()) return MHD_ST_ABORTED;
             if (nP < 0) {
                 const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
                 PROF_ADD(5)

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) MHD_REGS void bench_kernel(const double* m, int
     const int lane = threadIdx.x;
     if (lane < 2 * nl + 1) mm[lane] = m[lane];
     __syncthreads();
-    build_layer_table(T, mm, nl, 1.75, lane);
+    build_layer_table(T, mm, nl, 1.75, lane, nl);
     const double omega = TWOPI / (0.05 + 0.005 * (lane % 40));
     double c = 0.25 + 0.01 * lane, acc = 0.0;
     const long long t0 = clock64();
