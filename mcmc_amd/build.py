@@ -15,7 +15,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 # A test build: every third interpolated root of the deferring period search is replaced by a
 # wrong one, so that the later verification of the inferred halvings fails and the periods are
-# searched again.  Results must be those of the product build (tests/test_gpu_deferred_tails.py).
+# searched again; and the candidates of the Metropolis-Hastings kernels are told to give their
+# curves up without reason, so that their steps have to be run again.  Results must be those of
+# the product build (tests/test_gpu_deferred_tails.py).
 OUT_SABOTAGE = os.path.join(HERE, "lib", "libmcmc_amd_sabotage.so")
 
 
@@ -36,7 +38,7 @@ def build(force=False, verbose=False):
 
 
 def build_test_variants(force=False, verbose=False):
-    return _compile(OUT_SABOTAGE, ["-DMHD_DEFER_SABOTAGE"], force, verbose)
+    return _compile(OUT_SABOTAGE, ["-DMHD_DEFER_SABOTAGE", "-DMHD_ABORT_SABOTAGE"], force, verbose)
 
 
 if __name__ == "__main__":

@@ -549,7 +549,10 @@ __host__ __device__ inline SchedView sched_view(void* buf, int B)
 #define SCHED_PHASES_N 2
 #endif
 constexpr int SCHED_PHASES = SCHED_PHASES_N;
-constexpr int SCHED_PHASES_MIN_STEPS = 96;  // calls of fewer steps are one launch
+#ifndef SCHED_MIN_STEPS
+#define SCHED_MIN_STEPS 96
+#endif
+constexpr int SCHED_PHASES_MIN_STEPS = SCHED_MIN_STEPS;  // calls of fewer steps are one launch
 #ifndef PHASE_DEADLINE_LATER
 #define PHASE_DEADLINE_LATER 1.0f  // later deadlines, in units of the median unfinished chain's
 #endif
@@ -659,6 +662,18 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
 // whose two waves never meet in a barrier).
 #ifndef ABORT_MOOT
 #define ABORT_MOOT 1
+#endif
+// Test build: requests to give a curve up that are NOT justified -- every wave that finishes a
+// curve sends one to the waves after it, whatever its accept test says, and in every third round
+// the later waves find one before they start.  Steps whose curve is missing when the settlement
+// reaches them are run again, so nothing but the time taken may change
+// (tests/test_gpu_deferred_tails.py).  g_abort_stats: curves given up, and how many of them the
+// settlement reached.
+#ifdef MHD_ABORT_SABOTAGE
+constexpr bool ABORT_SABOTAGE = true;
+__device__ unsigned long long g_abort_stats[2];
+#else
+constexpr bool ABORT_SABOTAGE = false;
 #endif
 template <int NW>
 __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
@@ -886,6 +901,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         g_blk[ib * 8 + 5] = ((unsigned long long)s << 32) | (unsigned long long)nw;
     if (writer && lane == 0 && ib < 1024 && s == 0) g_times[2 * (1024 + ib)] = (unsigned long long)wall_clock64();
 #endif
+    int round_no = 0;
     while (s < S) {
         // ---- this wave's candidate: the (w-w0+1)-th proposal from step s on that passes the
         // bounds
@@ -908,7 +924,8 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         int st = MHD_ST_BOUNDS, trouble = 0;
         double lnew = 0.0;
         EvalCount cnt = {0, 0};
-        if (lane == 0) g_PS.abort = 0;
+        if (lane == 0) g_PS.abort = (ABORT_SABOTAGE && w > w0 && round_no % 3 == 1) ? 1 : 0;
+        ++round_no;
         if (jc < S) {
             build_layer_table(T, test[w], nl, p.vpvs, lane, nlmax);
             if (policy.predicted()) {
@@ -929,8 +946,12 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             // A candidate that passes its accept test ends the round's steps wherever it is
             // reached, and if it is not reached an earlier one did: either way the candidates
             // after it are not needed, and their waves are told to give their curves up.
-            if (ABORT_MOOT && st == MHD_ST_OK && w + 1 < w0 + nw && accept_test(lnew, jc) && lane == 0)
+            if (ABORT_MOOT && w + 1 < w0 + nw && lane == 0 &&
+                (ABORT_SABOTAGE || (st == MHD_ST_OK && accept_test(lnew, jc))))
                 for (int c = w + 1; c < w0 + nw; ++c) g_PS_OF(c).abort = 1;
+#ifdef MHD_ABORT_SABOTAGE
+            if (st == MHD_ST_ABORTED && lane == 0) atomicAdd(&g_abort_stats[0], 1ull);
+#endif
         }
         if (lane == 0) {
             r_step[w] = jc;
@@ -966,7 +987,12 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             if (j >= S) break;
             // (a curve that was given up is never reached: a candidate before it was accepted.
             // Should it be, the step is simply run again in the next round.)
-            if (r_st[c] == MHD_ST_ABORTED) break;
+            if (r_st[c] == MHD_ST_ABORTED) {
+#ifdef MHD_ABORT_SABOTAGE
+                if (writer && lane == 0) atomicAdd(&g_abort_stats[1], 1ull);
+#endif
+                break;
+            }
             begin_step();
             lit += r_lit[c];
             s = j + 1;
@@ -1174,6 +1200,16 @@ int mhd_debug_profile_hi(unsigned long long* out16)
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long), 16 * sizeof(unsigned long long));
     return 0;
+}
+#endif
+
+#ifdef MHD_ABORT_SABOTAGE
+int mhd_debug_aborts(unsigned long long* out2)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+        e = hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_abort_stats), 2 * sizeof(unsigned long long));
+    return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_debug_aborts");
 }
 #endif
 

@@ -1,7 +1,10 @@
 """Run by tests/test_gpu_deferred_tails.py in a process of its own, with MCMC_AMD_LIB naming the
 test build of the library in which every third interpolated root of the deferring period search
 is wrong: the verification of the inferred halvings must catch each of them and the periods be
-searched again, so curves, evaluation counts, decisions and states are still the oracle's."""
+searched again, so curves, evaluation counts, decisions and states are still the oracle's.
+The same build tells the candidates of the multi-candidate kernels to give their curves up without
+reason (every wave that finishes asks the later ones to, and every third round they find the request
+before they start): the steps whose curves are missing are run again and nothing else changes."""
 import os
 import sys
 
@@ -76,8 +79,14 @@ def main():
         assert np.array_equal(ch.pred.cpu().numpy(), state.pred)
         np.testing.assert_allclose(ch.logL.cpu().numpy(), state.logL, rtol=1e-9)
         assert int(ch.n_evals[0]) == lit, (search, candidates, int(ch.n_evals[0]), lit)
+    # the unjustified requests were at work: curves were given up, and some of them were needed
+    import ctypes
+    stats = (ctypes.c_ulonglong * 2)()
+    assert L.lib().mhd_debug_aborts(stats) == 0
+    assert stats[0] > 100 and stats[1] > 20, list(stats)
     print("sabotage check ok: executed / sequential evaluations %.1f (sequential search), %.1f "
-          "(predicted)" % (execs[1] / olit, execs[2] / olit))
+          "(predicted); %d curves given up on request, %d of them needed and run again"
+          % (execs[1] / olit, execs[2] / olit, stats[0], stats[1]))
 
 
 if __name__ == "__main__":
