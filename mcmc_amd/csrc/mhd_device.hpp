@@ -329,7 +329,7 @@ __device__ __forceinline__ void osc_or_evan2(const double k[2], const double xk[
         if (arg[0] < 1.0e5 && arg[1] < 1.0e5) {
             double sn[2], cn[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) sincos_pio2(arg[u], sn[u], cn[u]);
+            for (int u = 0; u < 2; ++u) sincos_pio2<true>(arg[u], sn[u], cn[u]);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 cs[u] = cn[u];
@@ -350,7 +350,7 @@ __device__ __forceinline__ void osc_or_evan2(const double k[2], const double xk[
             arg[u] = r[u] * dpth;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) e1[u] = exp_neg(fmin(arg[u], 700.0));
+        for (int u = 0; u < 2; ++u) e1[u] = exp_neg<true>(fmin(arg[u], 700.0));
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             em[u] = e1[u];

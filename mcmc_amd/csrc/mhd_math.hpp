@@ -27,20 +27,25 @@ MHD_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c)
 // a * b + k for a constant k of a polynomial.  On the device the instruction is written out:
 // left to itself the compiler turns every Horner step into a register copy of the constant
 // followed by a two-address multiply-add, a third of the instructions of sincos and exp.
-#ifndef MHD_POLY_CONST
-#define MHD_POLY_CONST "v"
-#endif
+// SK: the constant in scalar registers (set up by scalar instructions inside the loop, which
+// cost the vector pipe nothing) instead of vector registers; the better choice where vector
+// registers are short, as in the evaluation of two abscissae per lane.
+template <bool SK>
 MHD_HD double fma_k(double a, double b, double k)
 {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MHD_POLY_PLAIN)
     double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), MHD_POLY_CONST(k));
+    if (SK)
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+    else
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(k));
     return d;
 #else
     return __builtin_fma(a, b, k);
 #endif
 }
 
+template <bool SK = false>
 MHD_HD void sincos_pio2(double x, double& s, double& c)
 {
     // pi/2 = P1 + P2 + P3 (each the nearest double of the running remainder)
@@ -59,20 +64,20 @@ MHD_HD void sincos_pio2(double x, double& s, double& c)
                  S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     double ps = fma_(z, S6, S5);
-    ps = fma_k(z, ps, S4);
-    ps = fma_k(z, ps, S3);
-    ps = fma_k(z, ps, S2);
-    ps = fma_k(z, ps, S1);
+    ps = fma_k<SK>(z, ps, S4);
+    ps = fma_k<SK>(z, ps, S3);
+    ps = fma_k<SK>(z, ps, S2);
+    ps = fma_k<SK>(z, ps, S1);
     const double sr = fma_(r * z, ps, r);
     // cos kernel
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     double pc = fma_(z, C6, C5);
-    pc = fma_k(z, pc, C4);
-    pc = fma_k(z, pc, C3);
-    pc = fma_k(z, pc, C2);
-    pc = fma_k(z, pc, C1);
+    pc = fma_k<SK>(z, pc, C4);
+    pc = fma_k<SK>(z, pc, C3);
+    pc = fma_k<SK>(z, pc, C2);
+    pc = fma_k<SK>(z, pc, C1);
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double cr = w + (((1.0 - w) - hz) + z * z * pc);
@@ -83,6 +88,7 @@ MHD_HD void sincos_pio2(double x, double& s, double& c)
     c = ((q + 1) & 2) ? -cs : cs;
 }
 
+template <bool SK = false>
 MHD_HD double exp_neg(double y)
 {
     // exp(-y), 0 <= y <= 700
@@ -94,16 +100,16 @@ MHD_HD double exp_neg(double y)
     r = fma_(-nf, LN2_LO, r);
     // e^r, |r| <= ln2/2: Taylor to degree 13 (remainder < 5e-18)
     double p = 1.0 / 6227020800.0;
-    p = fma_k(p, r, 1.0 / 479001600.0);
-    p = fma_k(p, r, 1.0 / 39916800.0);
-    p = fma_k(p, r, 1.0 / 3628800.0);
-    p = fma_k(p, r, 1.0 / 362880.0);
-    p = fma_k(p, r, 1.0 / 40320.0);
-    p = fma_k(p, r, 1.0 / 5040.0);
-    p = fma_k(p, r, 1.0 / 720.0);
-    p = fma_k(p, r, 1.0 / 120.0);
-    p = fma_k(p, r, 1.0 / 24.0);
-    p = fma_k(p, r, 1.0 / 6.0);
+    p = fma_k<SK>(p, r, 1.0 / 479001600.0);
+    p = fma_k<SK>(p, r, 1.0 / 39916800.0);
+    p = fma_k<SK>(p, r, 1.0 / 3628800.0);
+    p = fma_k<SK>(p, r, 1.0 / 362880.0);
+    p = fma_k<SK>(p, r, 1.0 / 40320.0);
+    p = fma_k<SK>(p, r, 1.0 / 5040.0);
+    p = fma_k<SK>(p, r, 1.0 / 720.0);
+    p = fma_k<SK>(p, r, 1.0 / 120.0);
+    p = fma_k<SK>(p, r, 1.0 / 24.0);
+    p = fma_k<SK>(p, r, 1.0 / 6.0);
     p = fma_(p, r, 0.5);
     p = fma_(p, r, 1.0);
     p = fma_(p, r, 1.0);
