@@ -1256,9 +1256,15 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
                 auto back = [&](int k, double ck) -> bool {
                     return uni(fabs(ck - uniform_value(S.lo[k])) <= 2.0e-6 * ck);
                 };
-                const int kdone = sequential_run(wave, t, tscale, kstart, klast, dc, c, s1st, cnt, back);
+                // (a request to give the curve up ends the run like an answer that is back)
+                auto back_or_given_up = [&](int k, double ck) -> bool {
+                    return back(k, ck) || abort_requested();
+                };
+                const int kdone = sequential_run(wave, t, tscale, kstart, klast, dc, c, s1st, cnt,
+                                                 back_or_given_up);
                 PROF_ADD(4)
                 if (kdone < 0) return MHD_ST_NOROOT;
+                if (abort_requested()) return MHD_ST_ABORTED;
                 bool resynced = false;
                 if (kdone > kstart) {
                     cr = uniform_value(c[kdone - 1]);
