@@ -125,7 +125,9 @@ typedef struct mhd_problem {
                            runs at the same time: 2 (default; with `sched` the
                            library also picks 4 or 1 per chain), 4, or 1.  The steps
                            are settled in order, a later candidate counting only if
-                           the earlier ones were rejected.  sample_prior uses 1. */
+                           the earlier ones were rejected (and giving its forward
+                           model up as soon as an earlier one is known to be
+                           accepted).  sample_prior uses 1. */
 } mhd_problem_t;
 
 /*
