@@ -1,6 +1,7 @@
 """Parallel tempering on the device: the exchange sweep kernel against its host restatement, and
-a tempered Inversion.random_walk (8 temperatures x 16 ladders) against a host simulation that
-drives the oracle's MH step and the oracle's sweep with the same draws."""
+a tempered Inversion.random_walk (8 temperatures x 16 ladders; 64 x 16, one GPU's share of the
+sharded 64 x 128 configuration) against a host simulation that drives the oracle's MH step and
+the oracle's sweep with the same draws."""
 import numpy as np
 import pytest
 
@@ -49,22 +50,30 @@ def test_sweep_kernel_matches_host_restatement(oracle, layout, n_temps, n_ladder
                                   np.tile(ladder, (n_ladders, 1)))
 
 
+# the small case, and one GPU's share of the sharded 64 x 128 configuration at full size
+SMALL = (3, 20, 8, 16, 12, 3, 6, np.array([0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0]))
+SHARD = (6, 40, 64, 16, 6, 5, 3,
+         np.array([0.01, 0.02, 0.04, 0.06, 0.08, 0.10, 0.2, 0.3, 0.45, 0.6, 0.8, 1.0, 1.5]))
+
+
 @pytest.mark.parametrize("layout", ["ladder", "rung"])
-def test_tempered_random_walk_matches_host_simulation(oracle, tmp_path, layout):
-    """8 temperatures x 16 ladders, 12 outer steps of 3 MH steps with a sweep after each: states,
-    betas and the recorded history equal those of the oracle driven with the same draws."""
+@pytest.mark.parametrize("case", [SMALL, SHARD], ids=["8x16", "64x16_6layers_40periods"])
+def test_tempered_random_walk_matches_host_simulation(oracle, tmp_path, layout, case):
+    """8 temperatures x 16 ladders (3 layers, 20 periods), 12 outer steps of 3 MH steps with a
+    sweep after each; and 64 temperatures x 16 ladders (6 layers, 40 periods: the 1024 replicas
+    one of eight GPUs holds of 64 x 128), 6 outer steps of 5 MH steps: states, betas and the
+    recorded history equal those of the oracle driven with the same draws."""
     from mcmc_amd.inversion import Data, Inversion
-    nl, P, NT, NLAD = 3, 20, 8, 16
+    nl, P, NT, NLAD, n_mcmc, n_thin, n_chunk, true_m = case
     R = NT * NLAD
     mp = _mp(nl)
     periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
-    true_m = np.array([0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0])
     rng = np.random.default_rng(2)
     obs = oracle.forward(true_m, nl, 1.75, periods)[1] + 0.025 * rng.standard_normal(P)
     noise = {"std": 0.025}
     data = Data(periods, obs, "normal", noise)
     data.model_true = true_m
-    n_mcmc, n_thin, n_chunk = 12, 3, 6
+    oracle.set_threads(8)
     np.random.seed(9)
     inv = Inversion(data, mp, "normal", noise, n_burn=0, n_chunk=n_chunk, n_mcmc=n_mcmc,
                     n_thin=n_thin, n_chains=NLAD, n_temps=NT, beta_spacing_factor=1.3,
@@ -104,6 +113,7 @@ def test_tempered_random_walk_matches_host_simulation(oracle, tmp_path, layout):
             acc, prop = acc + a, prop + p
             hist_m.append(st.m.copy())
             hist_beta.append(betas.copy())
+    oracle.set_threads(1)
     np.testing.assert_array_equal(inv.betas, betas)
     np.testing.assert_array_equal(inv.state.m.cpu().numpy(), st.m)
     np.testing.assert_allclose(inv.state.logL.cpu().numpy(), st.logL, rtol=1e-9)
