@@ -663,6 +663,27 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
 #ifndef ABORT_MOOT
 #define ABORT_MOOT 1
 #endif
+#ifndef SPEC_TREE
+#define SPEC_TREE 1
+#endif
+// (a candidate that follows an acceptance has a poorer guide for its curve -- the current
+// curve is two moves away -- and takes longer: with four candidates the first of them joins
+// the rejection chain later than its probability alone says, 0.32)
+#ifndef SPEC_FIRST_A
+#define SPEC_FIRST_A 0.42f
+#endif
+#ifndef SPEC_BIAS
+#define SPEC_BIAS 0.0f
+#endif
+#ifndef SPEC_PACC_START
+#define SPEC_PACC_START 0.3f
+#endif
+#ifndef SPEC_PACC_WINDOW
+#define SPEC_PACC_WINDOW 32
+#endif
+#ifndef SPEC_PACC_KEPT
+#define SPEC_PACC_KEPT 8
+#endif
 // Test build: requests to give a curve up that are NOT justified -- every wave that finishes a
 // curve sends one to the waves after it, whatever its accept test says, and in every third round
 // the later waves find one before they start.  Steps whose curve is missing when the settlement
@@ -696,6 +717,8 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     __shared__ double scratch[NW][3 * MAXP];  // two phase curves (group velocity), likelihood terms
     __shared__ double ghint_[NG][2 * MAXP];   // group velocity: the two phase curves of the current state
     __shared__ int ghint_ok_[NG];
+    __shared__ double mw_[NW][MAXNP];   // the state a wave's candidate starts from when that is
+    __shared__ double mnw_[NW][MAXNP];  // not the chain's current one: parameters, normalised
     __shared__ int r_step[NW], r_st[NW], r_trouble[NW], r_stop[NW];
     __shared__ double r_logL[NW];
     __shared__ unsigned long long r_lit[NW];
@@ -776,6 +799,20 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     const bool phase_hint = p.itype == MHD_PHASE || p.itype == MHD_PHASE_AND_ELL;
     const bool group_kind = p.itype == MHD_GROUP || p.itype == MHD_PHASE_AND_GROUP;
     SearchPolicy policy = {search == 2 ? 0 : 3, 0, phase_hint ? 0 : 3};
+    // share of the chain's forwards that were accepted lately (which candidates a round runs
+    // depends on it, see below); kept between launches beside the search level
+    // (a running mean that starts from SPEC_PACC_START, or from what the last launch left,
+    // and becomes an exponential average over the last SPEC_PACC_WINDOW forwards: quick to
+    // learn in a chain's first steps, steady in a long run)
+    float pacc = SPEC_PACC_START;
+    int pacc_n = 2;
+    if (keeps) {
+        const int q = (int)sched_view(ch.sched, B).level[ib] >> 2;
+        if (q > 0) {
+            pacc = (float)q * (1.0f / 63.0f);
+            pacc_n = SPEC_PACC_KEPT;
+        }
+    }
     if (search == 2 && keeps) {
         int lv = (int)sched_view(ch.sched, B).level[ib] & 3;
         if (lv > policy.max_level) lv = policy.max_level;
@@ -908,17 +945,77 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
 #ifdef MHD_PROFILE
         const long long _r0 = clock64();
 #endif
-        int jc = S, found = 0, kkc = 0;
+        // Which proposals the waves of the chain work on.  A candidate is a node of the tree of
+        // what the chain may do next: its path says, for each candidate before it on the way
+        // from the current state, whether that one is taken to be accepted (bit i of the path:
+        // the i-th) -- its proposal then starts from that candidate's parameters -- or rejected.
+        // The first wave takes the root (the next proposal from the current state); the others
+        // take the likeliest nodes given the share of forwards the chain accepted lately:
+        // after rejections only (R, RR, RRR) for a chain that rejects most, after acceptances
+        // (A, AA, AAA) for one that accepts most -- two or three accepted steps then settle in
+        // one round -- and mixtures in between.  Every node's draws are those of its steps, so
+        // whichever path the settlement follows, the chain is the sequential one.
+        int nlen[NW], nbits[NW];
+        nlen[0] = 0;
+        nbits[0] = 0;
+        if (NW == 2) {
+            nlen[1] = 1;
+            nbits[1] = (SPEC_TREE && pacc > 0.5f + SPEC_BIAS) ? 1 : 0;
+        } else {
+            const int kind = !SPEC_TREE ? 0 : (pacc < SPEC_FIRST_A ? 0 : (pacc < 0.5f + SPEC_BIAS ? 1 : (pacc < 0.68f + SPEC_BIAS ? 2 : 3)));
+            // kind 0: R RR RRR   1: R RR A   2: A R AA   3: A AA AAA
+            nlen[1] = 1;
+            nbits[1] = kind >= 2 ? 1 : 0;
+            nlen[2] = kind == 2 ? 1 : 2;
+            nbits[2] = kind == 3 ? 3 : 0;
+            nlen[3] = kind == 1 ? 1 : (kind == 2 ? 2 : 3);
+            nbits[3] = kind == 0 ? 0 : (kind == 1 ? 1 : (kind == 2 ? 3 : 7));
+        }
+        const int wi = w - w0;
+        int mylen = 0, mybits = 0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q)
+            if (q == wi) {
+                mylen = nlen[q];
+                mybits = nbits[q];
+            }
+        // walk the path: the proposals of the candidates before this one, from the states the
+        // path gives them, then this wave's own
+        int jc = S, kkc = 0;
         double czc = 0.0;
-        for (int j = s; j < S; ++j) {
-            const int kk = idx[(size_t)j * B + ib];
-            const double cz = cauchy[(size_t)j * B + ib];
-            if (propose_wave(frame, mn, kk, cz, test[w], tmp[w], lane) == MHD_ST_OK &&
-                ++found == w - w0 + 1) {
-                jc = j;
-                czc = cz;
-                kkc = kk;
-                break;
+        {
+            const double* cur_m = m;
+            const double* cur_mn = mn;
+            int pos = s;
+            for (int i = 0; i <= mylen; ++i) {
+                int ji = S;
+                for (int j = pos; j < S; ++j) {
+                    const int kk = idx[(size_t)j * B + ib];
+                    const double cz = cauchy[(size_t)j * B + ib];
+                    if (propose_wave(frame, cur_mn, kk, cz, test[w], tmp[w], lane) == MHD_ST_OK) {
+                        ji = j;
+                        czc = cz;
+                        kkc = kk;
+                        break;
+                    }
+                }
+                if (ji >= S) break;  // the steps run out on the way: nothing for this wave
+                if (i == mylen) {
+                    jc = ji;
+                    break;
+                }
+                if ((mybits >> i) & 1) {
+                    // taken to be accepted: the state moves as the settlement would move it
+                    if (lane < NP) {
+                        const double mv = frame.used(lane) ? test[w][lane] : cur_m[lane];
+                        mw_[w][lane] = mv;
+                        mnw_[w][lane] = (mv - lo[lane]) / rg[lane];
+                    }
+                    wave_sync();
+                    cur_m = mw_[w];
+                    cur_mn = mnw_[w];
+                }
+                pos = ji + 1;
             }
         }
         int st = MHD_ST_BOUNDS, trouble = 0;
@@ -931,7 +1028,9 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
                                        scratch[w], cnt, policy.stepwise(), pred, ghint,
-                                       !hinted ? 0 : (fabs(czc) <= hlim[kkc] ? 2 : 1));
+                                       // (after an acceptance on the path the current curve is
+                                       // two moves away: a guide for the windows only)
+                                       !hinted ? 0 : (mybits == 0 && fabs(czc) <= hlim[kkc] ? 2 : 1));
                 trouble = st == MHD_ST_ABORTED ? 0 : __builtin_amdgcn_readfirstlane(g_PS.trouble);
                 // (the waves of a chain update the limits unordered; they are heuristics)
                 if (lane == 0 && st != MHD_ST_ABORTED)
@@ -946,8 +1045,20 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             // A candidate that passes its accept test ends the round's steps wherever it is
             // reached, and if it is not reached an earlier one did: either way the candidates
             // after it are not needed, and their waves are told to give their curves up.
-            if (ABORT_MOOT && w + 1 < w0 + nw && lane == 0 &&
-                (ABORT_SABOTAGE || (st == MHD_ST_OK && accept_test(lnew, jc))))
+            // (For a candidate that follows rejections only the accept test is known here, the
+            // chain's likelihood being the current one.  Passed: whatever takes it to be
+            // rejected is moot -- if it is reached it is accepted, if not, an earlier one was.
+            // Failed: whatever takes it to be accepted is moot, by the same argument.)
+            if (ABORT_MOOT && nw > 1 && mybits == 0 && st != MHD_ST_ABORTED && !ABORT_SABOTAGE) {
+                const int out = (st == MHD_ST_OK) ? accept_test(lnew, jc) : 0;
+#pragma unroll
+                for (int q = 0; q < NW; ++q)
+                    if (q != wi && q < nw && nlen[q] > mylen &&
+                        (nbits[q] & ((1 << mylen) - 1)) == 0 && ((nbits[q] >> mylen) & 1) != out &&
+                        lane == 0)
+                        g_PS_OF(w0 + q).abort = 1;
+            }
+            if (ABORT_SABOTAGE && lane == 0)
                 for (int c = w + 1; c < w0 + nw; ++c) g_PS_OF(c).abort = 1;
 #ifdef MHD_ABORT_SABOTAGE
             if (st == MHD_ST_ABORTED && lane == 0) atomicAdd(&g_abort_stats[0], 1ull);
@@ -978,15 +1089,22 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             ran += (r_step[c] < S);
             trouble2 |= r_trouble[c] >= (hinted ? HINTED_TROUBLE_MIN : 2);
         }
-        for (int c = w0; c < w0 + nw; ++c) {
-            const int j = r_step[c];  // <= S, increasing with c
+        // follow the tree from the root by what really happens
+        int cl = 0, cb = 0;
+        for (int n = 0; n < nw; ++n) {
+            int c = -1;
+#pragma unroll
+            for (int q = 0; q < NW; ++q)
+                if (q < nw && nlen[q] == cl && nbits[q] == cb) c = w0 + q;
+            if (c < 0) break;         // nobody ran this node
+            const int j = r_step[c];  // <= S
             for (; s < j; ++s) {
                 begin_step();
                 book(s, MHD_ST_BOUNDS, 0);
             }
             if (j >= S) break;
-            // (a curve that was given up is never reached: a candidate before it was accepted.
-            // Should it be, the step is simply run again in the next round.)
+            // (a curve that was given up is never reached: its node is off the path the chain
+            // takes.  Should it be, the step is simply run again in the next round.)
             if (r_st[c] == MHD_ST_ABORTED) {
 #ifdef MHD_ABORT_SABOTAGE
                 if (writer && lane == 0) atomicAdd(&g_abort_stats[1], 1ull);
@@ -996,8 +1114,11 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             begin_step();
             lit += r_lit[c];
             s = j + 1;
-            // an acceptance: the later candidates started from a state that no longer holds
-            if (settle(c, j)) break;
+            const int acc = settle(c, j);
+            pacc_n += pacc_n < SPEC_PACC_WINDOW;
+            pacc += ((float)acc - pacc) / (float)pacc_n;
+            cb |= acc << cl;
+            ++cl;
         }
 #ifdef MHD_PROFILE
         if (writer && lane == 0 && ib < 1024) {
@@ -1024,7 +1145,12 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
                                        ((unsigned long long)NW << 4) | ((unsigned long long)split << 3) | (unsigned long long)nw;
 #endif
     if (writer && lane == 0 && keeps) {
-        if (search == 2) sched_view(ch.sched, B).level[ib] = (unsigned char)policy.level;
+        {
+            int q = (int)(pacc * 63.0f + 0.5f);
+            q = q < 1 ? 1 : (q > 63 ? 63 : q);
+            const int lv = search == 2 ? policy.level : ((int)sched_view(ch.sched, B).level[ib] & 3);
+            sched_view(ch.sched, B).level[ib] = (unsigned char)(lv | (q << 2));
+        }
         if (scheduled) sched_view(ch.sched, B).progress[ib] = s;
         if (s > s_begin) {
             // (a launch that did only part of the call's steps counts by that part)
