@@ -124,10 +124,13 @@ typedef struct mhd_problem {
     int32_t candidates; /* proposals of one chain whose forward models mhd_mh_steps
                            runs at the same time: 2 (default; with `sched` the
                            library also picks 4 or 1 per chain), 4, or 1.  The steps
-                           are settled in order, a later candidate counting only if
-                           the earlier ones were rejected (and giving its forward
-                           model up as soon as an earlier one is known to be
-                           accepted).  sample_prior uses 1. */
+                           are settled in order.  The candidates are the likeliest
+                           next steps of the chain: proposals from the current
+                           state (counting if the ones before them are rejected)
+                           and, for chains that accept most proposals, proposals
+                           from an earlier candidate's state (counting if that one
+                           is accepted); a candidate that can no longer count
+                           gives its forward model up.  sample_prior uses 1. */
 } mhd_problem_t;
 
 /*

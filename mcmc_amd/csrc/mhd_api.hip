@@ -672,6 +672,9 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
 #ifndef SPEC_FIRST_A
 #define SPEC_FIRST_A 0.42f
 #endif
+#ifndef SPEC_HINT_SMALL
+#define SPEC_HINT_SMALL 1
+#endif
 #ifndef SPEC_BIAS
 #define SPEC_BIAS 0.0f
 #endif
@@ -983,6 +986,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         // path gives them, then this wave's own
         int jc = S, kkc = 0;
         double czc = 0.0;
+        bool small_moves = true;  // every move on the way is one that predict_hint copes with
         {
             const double* cur_m = m;
             const double* cur_mn = mn;
@@ -1005,6 +1009,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
                     break;
                 }
                 if ((mybits >> i) & 1) {
+                    small_moves = small_moves && fabs(czc) <= hlim[kkc];
                     // taken to be accepted: the state moves as the settlement would move it
                     if (lane < NP) {
                         const double mv = frame.used(lane) ? test[w][lane] : cur_m[lane];
@@ -1030,7 +1035,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
                                        scratch[w], cnt, policy.stepwise(), pred, ghint,
                                        // (after an acceptance on the path the current curve is
                                        // two moves away: a guide for the windows only)
-                                       !hinted ? 0 : (mybits == 0 && fabs(czc) <= hlim[kkc] ? 2 : 1));
+                                       !hinted ? 0 : ((mybits == 0 || SPEC_HINT_SMALL) && small_moves && fabs(czc) <= hlim[kkc] ? 2 : 1));
                 trouble = st == MHD_ST_ABORTED ? 0 : __builtin_amdgcn_readfirstlane(g_PS.trouble);
                 // (the waves of a chain update the limits unordered; they are heuristics)
                 if (lane == 0 && st != MHD_ST_ABORTED)
