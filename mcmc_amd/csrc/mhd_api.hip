@@ -687,15 +687,16 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
 #ifndef SPEC_PACC_KEPT
 #define SPEC_PACC_KEPT 8
 #endif
-// Test build: requests to give a curve up that are NOT justified -- every wave that finishes a
+// Test build: every shape of the candidates' tree in turn, whatever the chain accepts; and
+// requests to give a curve up that are NOT justified -- every wave that finishes a
 // curve sends one to the waves after it, whatever its accept test says, and in every third round
 // the later waves find one before they start.  Steps whose curve is missing when the settlement
 // reaches them are run again, so nothing but the time taken may change
 // (tests/test_gpu_deferred_tails.py).  g_abort_stats: curves given up, and how many of them the
-// settlement reached.
+// settlement reached, steps settled by a candidate that follows an acceptance.
 #ifdef MHD_ABORT_SABOTAGE
 constexpr bool ABORT_SABOTAGE = true;
-__device__ unsigned long long g_abort_stats[2];
+__device__ unsigned long long g_abort_stats[3];
 #else
 constexpr bool ABORT_SABOTAGE = false;
 #endif
@@ -961,11 +962,13 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         int nlen[NW], nbits[NW];
         nlen[0] = 0;
         nbits[0] = 0;
+        // (the test build runs every shape of the tree in turn, whatever the chain accepts)
+        const float psel = ABORT_SABOTAGE ? 0.2f + 0.25f * (float)(round_no & 3) : pacc;
         if (NW == 2) {
             nlen[1] = 1;
-            nbits[1] = (SPEC_TREE && pacc > 0.5f + SPEC_BIAS) ? 1 : 0;
+            nbits[1] = (SPEC_TREE && psel > 0.5f + SPEC_BIAS) ? 1 : 0;
         } else {
-            const int kind = !SPEC_TREE ? 0 : (pacc < SPEC_FIRST_A ? 0 : (pacc < 0.5f + SPEC_BIAS ? 1 : (pacc < 0.68f + SPEC_BIAS ? 2 : 3)));
+            const int kind = !SPEC_TREE ? 0 : (psel < SPEC_FIRST_A ? 0 : (psel < 0.5f + SPEC_BIAS ? 1 : (psel < 0.68f + SPEC_BIAS ? 2 : 3)));
             // kind 0: R RR RRR   1: R RR A   2: A R AA   3: A AA AAA
             nlen[1] = 1;
             nbits[1] = kind >= 2 ? 1 : 0;
@@ -1120,6 +1123,9 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             lit += r_lit[c];
             s = j + 1;
             const int acc = settle(c, j);
+#ifdef MHD_ABORT_SABOTAGE
+            if (writer && lane == 0 && cb != 0) atomicAdd(&g_abort_stats[2], 1ull);
+#endif
             pacc_n += pacc_n < SPEC_PACC_WINDOW;
             pacc += ((float)acc - pacc) / (float)pacc_n;
             cb |= acc << cl;
@@ -1335,11 +1341,11 @@ int mhd_debug_profile_hi(unsigned long long* out16)
 #endif
 
 #ifdef MHD_ABORT_SABOTAGE
-int mhd_debug_aborts(unsigned long long* out2)
+int mhd_debug_aborts(unsigned long long* out2)  // out2[3]
 {
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess)
-        e = hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_abort_stats), 2 * sizeof(unsigned long long));
+        e = hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_abort_stats), 3 * sizeof(unsigned long long));
     return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_debug_aborts");
 }
 #endif

@@ -4,7 +4,9 @@ is wrong: the verification of the inferred halvings must catch each of them and 
 searched again, so curves, evaluation counts, decisions and states are still the oracle's.
 The same build tells the candidates of the multi-candidate kernels to give their curves up without
 reason (every wave that finishes asks the later ones to, and every third round they find the request
-before they start): the steps whose curves are missing are run again and nothing else changes."""
+before they start) and runs every shape of the candidates' tree in turn (candidates that follow
+acceptances as well as rejections, whatever the chains accept): the steps whose curves are missing
+are run again and nothing else changes."""
 import os
 import sys
 
@@ -81,12 +83,15 @@ def main():
         assert int(ch.n_evals[0]) == lit, (search, candidates, int(ch.n_evals[0]), lit)
     # the unjustified requests were at work: curves were given up, and some of them were needed
     import ctypes
-    stats = (ctypes.c_ulonglong * 2)()
+    # (and steps were settled by candidates that started from an earlier candidate's state:
+    # the build runs every shape of the candidates' tree in turn)
+    stats = (ctypes.c_ulonglong * 3)()
     assert L.lib().mhd_debug_aborts(stats) == 0
-    assert stats[0] > 100 and stats[1] > 20, list(stats)
+    assert stats[0] > 100 and stats[1] > 20 and stats[2] > 50, list(stats)
     print("sabotage check ok: executed / sequential evaluations %.1f (sequential search), %.1f "
-          "(predicted); %d curves given up on request, %d of them needed and run again"
-          % (execs[1] / olit, execs[2] / olit, stats[0], stats[1]))
+          "(predicted); %d curves given up on request, %d of them needed and run again; %d steps "
+          "settled by candidates that follow an acceptance"
+          % (execs[1] / olit, execs[2] / olit, stats[0], stats[1], stats[2]))
 
 
 if __name__ == "__main__":
