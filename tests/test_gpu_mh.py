@@ -113,6 +113,65 @@ def test_batched_steps_vs_oracle(oracle, n_layers, P, B, S):
     assert (stat == 1).any()   # bounds rejections were exercised
 
 
+def test_chains_that_accept_most_proposals_vs_oracle(oracle, candidates):
+    """Hot chains (beta down to 1e-4) and wide noise: nearly every valid proposal is accepted, so
+    the kernels run candidates that follow acceptances (several accepted steps settle in one
+    round).  Three calls in a row on one schedule: the share of accepted proposals that steers the
+    choice of candidates is carried from call to call.  Decisions, states, counters, histories
+    and the literal evaluation count are the oracle's."""
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    rng = np.random.default_rng(2024)
+    nl, P, B, S = 6, 40, 128, 30
+    NP = 2 * nl + 1
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
+    starts = []
+    while len(starts) < B:
+        x = oracle.sort_layers(rng.uniform(bounds[:, 0], bounds[:, 1]), nl)
+        if oracle.forward(x, nl, 1.75, periods)[0] == 0:
+            starts.append(x)
+    starts = np.array(starts)
+    obs = oracle.forward(starts[0], nl, 1.75, periods)[1] + 0.025 * rng.standard_normal(P)
+    noise = {"std": 0.2}
+    beta = rng.choice([1.0, 0.1, 1.0e-2, 1.0e-4], B)
+    prob = DeviceProblem(nl, 1.75, periods, obs, "normal", noise, bounds)
+    ch = DeviceChains(prob, starts, 0.02, beta=beta)
+    assert int((ch.init_likelihood() != 0).sum()) == 0
+    _, ovel, _ = oracle.forward_batch(starts, nl, 1.75, periods, nthreads=8)
+    ologL = np.array([oracle.loglik(obs, v, "normal", noise) for v in ovel])
+    ost = oracle.ChainState(starts, ologL, ovel, 0.02, bounds)
+    dev = prob.device
+    lit = n_acc = 0
+    oracle.set_threads(8)
+    for call in range(3):
+        idx = rng.integers(0, NP, (S, B)).astype(np.int32)
+        cauchy = np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5))
+        u_acc = rng.uniform(size=(S, B))
+        out = ch.steps(torch.tensor(idx, device=dev), torch.tensor(cauchy, device=dev),
+                       torch.tensor(u_acc, device=dev), hist_every=1)
+        acc = np.zeros((S, B), dtype=np.uint8)
+        stat = np.zeros((S, B), dtype=np.int32)
+        hist = np.zeros((S, B, NP))
+        for s in range(S):
+            acc[s], stat[s], ne = oracle.mh_step(ost, idx[s], cauchy[s], u_acc[s], nl, 1.75,
+                                                 periods, obs, "normal", noise, beta=beta)
+            hist[s] = ost.m
+            lit += ne
+        n_acc += int(acc.sum())
+        np.testing.assert_array_equal(out["accepted"].cpu().numpy(), acc)
+        np.testing.assert_array_equal(out["status"].cpu().numpy(), stat)
+        np.testing.assert_array_equal(out["hist_m"].cpu().numpy(), hist)
+        np.testing.assert_array_equal(ch.m.cpu().numpy(), ost.m)
+        np.testing.assert_allclose(ch.logL.cpu().numpy(), ost.logL, rtol=1e-9)
+        np.testing.assert_array_equal(ch.pred.cpu().numpy(), ost.pred)
+        np.testing.assert_array_equal(ch.counters.cpu().numpy(), ost.counters)
+    oracle.set_threads(1)
+    assert int(ch.n_evals[0]) == lit
+    valid = int((ost.counters[:, 0] + ost.counters[:, 1] - ost.counters[:, 2]).sum())
+    assert n_acc > 0.6 * valid, (n_acc, valid)   # the chains did accept most valid proposals
+
+
 def test_steps_of_chains_in_low_velocity_zone_models_vs_oracle(oracle):
     """Chains that start at models with strong low-velocity zones: their curves jump downwards
     between periods, so the curve of the current state is a poor guide for the candidate's and
