@@ -153,7 +153,8 @@ typedef struct mhd_chains {
     const double *beta;  /* device [B] tempering exponent, or NULL for 1      */
     void *sched;         /* device, mhd_sched_bytes(B) bytes, or NULL: scratch the
                             library keeps between calls of mhd_mh_steps (what each
-                            chain's steps cost last time) and within one (how far
+                            chain's steps cost last time, what share of its
+                            proposals it accepted) and within one (how far
                             each chain has got); zero it once, before the first
                             call.  With it a call is two launches: the first ends
                             at a deadline, the second gives the chains that are

@@ -520,7 +520,9 @@ struct SchedView {
                   // (diagnostics), [6..7] unused
     int* order;   // [B]
     int* progress;         // [B] steps of the current call each chain has done
-    unsigned char* level;  // [B] SearchPolicy level each chain ended its last launch with
+    unsigned char* level;  // [B] bits 0-1: SearchPolicy level each chain ended its last launch
+                           // with; bits 2-7: the share of its forwards it accepted lately, in
+                           // 63rds (0: not known yet), see mh_steps_multi_kernel
 };
 
 __host__ __device__ inline int sched_cap4(int B, int phase)
