@@ -551,10 +551,14 @@ __host__ __device__ inline SchedView sched_view(void* buf, int B)
 #define SCHED_PHASES_N 2
 #endif
 constexpr int SCHED_PHASES = SCHED_PHASES_N;
+// Calls of fewer steps are one launch.  (Measured with calls of 25 ... 60 steps: two launches
+// gain 14-17 % where the chains' durations are spread -- tempered ladders, chains far from the
+// data -- and lose 1-2 % on chains that have settled at the data; below some 24 steps a deadline
+// and a second launch cost more than they even out.)
 #ifndef SCHED_MIN_STEPS
-#define SCHED_MIN_STEPS 96
+#define SCHED_MIN_STEPS 24
 #endif
-constexpr int SCHED_PHASES_MIN_STEPS = SCHED_MIN_STEPS;  // calls of fewer steps are one launch
+constexpr int SCHED_PHASES_MIN_STEPS = SCHED_MIN_STEPS;
 #ifndef PHASE_DEADLINE_LATER
 #define PHASE_DEADLINE_LATER 1.0f  // later deadlines, in units of the median unfinished chain's
 #endif
@@ -1427,7 +1431,7 @@ static int mh_steps_launch(const mhd_problem_t* prob, const mhd_chains_t* chains
         DeviceState* sd = device_state(-1, create_state);
         if (!sd) return MHD_EHIP;
         const int slots = sd->cus * 8;  // two waves of these kernels per SIMD
-        // (a short call is one launch: a deadline and a second launch cost more than they even out)
+        // (a short call is one launch, see SCHED_MIN_STEPS)
         const int phases = n_steps >= SCHED_PHASES_MIN_STEPS ? SCHED_PHASES : 1;
         // the events are shared by the callers of this device: one call enqueues at a time
         std::lock_guard<std::mutex> lock(sd->mu);
