@@ -681,6 +681,9 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
 #ifndef SPEC_HINT_SMALL
 #define SPEC_HINT_SMALL 1
 #endif
+#ifndef SPEC_GROUP_PENALTY
+#define SPEC_GROUP_PENALTY 0.1f
+#endif
 #ifndef SPEC_BIAS
 #define SPEC_BIAS 0.0f
 #endif
@@ -969,7 +972,10 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         nlen[0] = 0;
         nbits[0] = 0;
         // (the test build runs every shape of the tree in turn, whatever the chain accepts)
-        const float psel = ABORT_SABOTAGE ? 0.2f + 0.25f * (float)(round_no & 3) : pacc;
+        // (group velocity is three curves per forward, and the guide of a candidate after an
+        // acceptance is poorer for each: such candidates have to be likelier to be worth it)
+        const float psel = ABORT_SABOTAGE ? 0.2f + 0.25f * (float)(round_no & 3)
+                                          : pacc - (group_kind ? SPEC_GROUP_PENALTY : 0.0f);
         if (NW == 2) {
             nlen[1] = 1;
             nbits[1] = (SPEC_TREE && psel > 0.5f + SPEC_BIAS) ? 1 : 0;
