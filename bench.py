@@ -149,6 +149,7 @@ def main():
     import torch.distributed as dist
     from mcmc_amd.engine import DeviceChains, DeviceProblem
     from mcmc_amd import _lib as L, engine as E
+    from mcmc_amd.inversion.inversion import all_gather_blocks
     E.set_default_tuning(search=args.search)
     E.set_default_tuning(candidates=args.candidates)
 
@@ -222,10 +223,7 @@ def main():
             if args.tempering:
                 full = chains.logL
                 if world > 1:
-                    if dist.get_backend() != "nccl":
-                        torch.cuda.synchronize()  # (the gloo stand-in copies through the host)
-                    dist.all_gather_into_tensor(logL_all, chains.logL)
-                    full = logL_all
+                    full = all_gather_blocks(logL_all, chains.logL)  # the sampler's collective
                 tempering_sweep(full, beta_all, u_swap[a // args.thin], args.temps,
                                 world * B // args.temps, 1, args.temps, swap_counts)
         return n_launch
@@ -307,7 +305,8 @@ def main():
                 "traffic": None,
                 "kernel": "one call of mhd_mh_steps = " + (
                     "%d x (schedule_kernel, then mh_steps_multi_kernel<4> and <2> side by side)"
-                    % (2 if min(args.chunk, K) >= 96 else 1) if args.candidates == 2
+                    % (2 if min(args.chunk, K) >= L.lib().mhd_sched_min_steps() else 1)
+                    if args.candidates == 2
                     else "mh_steps_multi_kernel<%d>" % args.candidates if args.candidates == 4
                     else "mh_steps_kernel") + "; launch_ms is the call, by HIP events on its stream",
                 "launch_ms": launch_s * 1e3,

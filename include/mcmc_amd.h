@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MHD_ABI_VERSION 4
+#define MHD_ABI_VERSION 5
 
 #define MHD_OK 0
 #define MHD_EINVAL (-22) /* bad argument (size beyond a compiled limit, NULL pointer) */
@@ -156,15 +156,41 @@ typedef struct mhd_chains {
                             chain's steps cost last time, what share of its
                             proposals it accepted) and within one (how far
                             each chain has got); zero it once, before the first
-                            call.  With it a call is two launches: the first ends
-                            at a deadline, the second gives the chains that are
-                            behind more candidates in flight; the chains that take
-                            longest get four candidates from the start.  Results
-                            do not depend on it; no counterpart in the reference */
+                            call.  It is used by calls with 64 <= B <= 4096 chains,
+                            candidates = 0 or 2 and sample_prior = 0: the chains
+                            that take longest get four candidates from the start,
+                            and a call of at least mhd_sched_min_steps() steps is
+                            two launches, the first ending at a deadline, the second
+                            giving the chains that are behind more candidates in
+                            flight (a shorter call is one launch).  Results do not
+                            depend on it; no counterpart in the reference */
 } mhd_chains_t;
 
 /* Size of mhd_chains_t.sched for B chains. */
 size_t mhd_sched_bytes(int32_t B);
+
+/* The number of steps from which a call of mhd_mh_steps that uses mhd_chains_t.sched is two
+ * launches instead of one (a diagnostic for callers that describe their launches; no
+ * counterpart in the reference). */
+int mhd_sched_min_steps(void);
+
+/*
+ * Optional per-step records of mhd_mh_steps beside hist_m / hist_logL / hist_pred, written at
+ * the same cadence (after every hist_every-th step), each NULL to skip: what
+ * Inversion.store_samples keeps per step besides the state
+ * (src/inversion/inversion.py:163-231, :448-487).  The reference stores rates; these are the
+ * counts they are made of (rate = count / (n_acc + n_rej), refreshed only while n_rej > 0,
+ * src/inversion/model.py:483, :520).
+ */
+typedef struct mhd_diag {
+    int64_t *hist_counters;     /* device [S/hist_every,B,5]: n_acc, n_rej, n_bounds_err,
+                                   n_physics_err, n_fm_err of the chain after the step   */
+    int64_t *hist_counters_ind; /* device [S/hist_every,B,NP,5]: the per-parameter
+                                   counters (needs mhd_chains_t.counters_ind)           */
+    double *hist_cov;           /* device [S/hist_every,B,NP,NP]: cov_mat = cov_mat_sum /
+                                   n_cov (zeros while n_cov = 0; model.py:278-281);
+                                   needs cov_sum and n_cov                              */
+} mhd_diag_t;
 
 int mhd_abi_version(void);
 const char *mhd_last_error(void);
@@ -233,15 +259,16 @@ int mhd_loglik_batch(const mhd_problem_t *prob, const double *pred /* device [B,
  * Optional outputs (NULL to skip): accepted[S,B] (uint8), status[S,B],
  * hist_m[S/hist_every,B,NP], hist_logL[S/hist_every,B], hist_pred[S/hist_every,B,ND]
  * written after every hist_every-th step (the per-step records of
- * Inversion.store_samples, src/inversion/inversion.py:431-457).  n_evals as in
- * mhd_forward_batch.
+ * Inversion.store_samples, src/inversion/inversion.py:431-457); diag (NULL to skip) names
+ * further records at the same cadence, see mhd_diag_t.  n_evals as in mhd_forward_batch.
  */
 int mhd_mh_steps(const mhd_problem_t *prob, const mhd_chains_t *chains, int32_t B,
                  int32_t n_steps, const int32_t *idx /* device [S,B] */,
                  const double *cauchy /* device [S,B] */, const double *u_acc /* device [S,B] */,
                  double T, int32_t rotate, int32_t sample_prior,
                  uint8_t *accepted, int32_t *status, int32_t hist_every, double *hist_m,
-                 double *hist_logL, double *hist_pred, uint64_t *n_evals, void *stream);
+                 double *hist_logL, double *hist_pred, const mhd_diag_t *diag,
+                 uint64_t *n_evals, void *stream);
 
 /*
  * mhd_mh_steps for callers that cannot allocate device memory (code under HIP
@@ -253,10 +280,18 @@ int mhd_mh_steps(const mhd_problem_t *prob, const mhd_chains_t *chains, int32_t 
  *   - B <= 4096 chains (MHD_EINVAL beyond);
  *   - mhd_init() must have been called for the current device (MHD_EINVAL
  *     otherwise): this entry point creates no stream, event or memory;
- *   - every call on a GPU uses that GPU's one array.  It is cleared (on
- *     `stream`) when a call comes with another B or other chains (chains->m)
- *     than the call before; calls that overlap in time on one GPU race on it and
- *     must be ordered by the caller.
+ *   - every call on a GPU uses that GPU's one array.  Whose chains its contents
+ *     belong to is told by B and the ADDRESS chains->m alone: a call with another
+ *     B or another chains->m than the call before first clears the array (a
+ *     memset on `stream`, enqueued under the same per-device lock as the launches);
+ *     a caller whose allocator hands a new set of chains the address of an old
+ *     one calls mhd_static_reset() in between (what the array holds are tuning
+ *     values only: results never depend on them).  Calls that overlap in time on
+ *     one GPU race on the array and must be ordered by the caller;
+ *   - under HIP graph capture the decision to clear is taken once, at capture
+ *     time: call mhd_static_reset() before the capture, so that the captured
+ *     calls find the array cleared and adopt their chains without a memset in
+ *     the graph (a captured memset would wipe the costs at every replay).
  */
 #define MHD_STATIC_MAX_CHAINS 4096
 int mhd_mh_steps_static(const mhd_problem_t *prob, const mhd_chains_t *chains, int32_t B,
@@ -265,7 +300,14 @@ int mhd_mh_steps_static(const mhd_problem_t *prob, const mhd_chains_t *chains, i
                         const double *u_acc /* device [S,B] */, double T, int32_t rotate,
                         int32_t sample_prior, uint8_t *accepted, int32_t *status,
                         int32_t hist_every, double *hist_m, double *hist_logL, double *hist_pred,
-                        uint64_t *n_evals, void *stream);
+                        const mhd_diag_t *diag, uint64_t *n_evals, void *stream);
+
+/*
+ * Clears the static scratch of the current device on `stream` (no allocation; mhd_init() must
+ * have been called): the next call of mhd_mh_steps_static adopts its chains without clearing
+ * again.  No counterpart in the reference.
+ */
+int mhd_static_reset(void *stream);
 
 /*
  * One parallel-tempering exchange sweep, Inversion.perform_tempering_swap
@@ -291,6 +333,18 @@ int mhd_tempering_sweep(const double *logL /* device [R] */, double *beta /* dev
                         const double *u /* device [n_ladders, n_temps-1] */, int32_t n_temps,
                         int32_t n_ladders, int64_t rung_stride, int64_t ladder_stride,
                         int64_t *counts, void *stream);
+
+/*
+ * Model.stepsize_tuning (src/inversion/model.py:538-556) for B chains: a proposal width grows
+ * by half where the acceptance rate is above 0.4 and is halved where it lies in (0, 0.2).  The
+ * rate is n_acc / (n_acc + n_rej) of chains->counters -- one rate per chain, every width of the
+ * chain scaled alike -- or, when chains->counters_ind is given (individual_acceptance), of each
+ * parameter's own counters; it counts as 0 until a proposal has been rejected (the reference
+ * refreshes its rates only while n_rej > 0, model.py:483, :520).  The reference defines the
+ * method and leaves its call (after every step, model.py:257) commented out.
+ */
+int mhd_stepsize_tuning(const mhd_problem_t *prob, const mhd_chains_t *chains, int32_t B,
+                        void *stream);
 
 /*
  * Model.update_covariance_matrix alone (src/inversion/model.py:263-282), used on

@@ -19,7 +19,7 @@ PHASE, GROUP, PHASE_AND_GROUP, PHASE_AND_ELL, ELL = 0, 1, 2, 3, 4
 NORMAL, ASYM_LAPLACE = 0, 1
 ROT_ACCUMULATE, ROT_FRAME = 1, 2
 MAX_LAYERS, MAX_PERIODS = 15, 128
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = (
     "mhd_abi_version",
@@ -27,11 +27,14 @@ EXPORTS = (
     "mhd_init",
     "mhd_debug_occupancy",
     "mhd_sched_bytes",
+    "mhd_sched_min_steps",
     "mhd_secular_batch",
     "mhd_forward_batch",
     "mhd_loglik_batch",
     "mhd_mh_steps",
     "mhd_mh_steps_static",
+    "mhd_static_reset",
+    "mhd_stepsize_tuning",
     "mhd_cov_accumulate",
     "mhd_tempering_sweep",
 )
@@ -57,6 +60,12 @@ class Chains(ctypes.Structure):
         ("counters", c_void_p), ("counters_ind", c_void_p), ("beta", c_void_p),
         ("sched", c_void_p),
     ]
+
+
+class Diag(ctypes.Structure):
+    """struct mhd_diag"""
+    _fields_ = [("hist_counters", c_void_p), ("hist_counters_ind", c_void_p),
+                ("hist_cov", c_void_p)]
 
 
 class MhdError(RuntimeError):
@@ -93,10 +102,14 @@ def lib():
                                     c_void_p, c_void_p]
     L.mhd_forward_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
     L.mhd_loglik_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p]
+    L.mhd_sched_min_steps.argtypes = []
+    L.mhd_sched_min_steps.restype = ctypes.c_int
     L.mhd_mh_steps.argtypes = [pp, cp, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_double,
                                c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p]
+                               c_void_p, ctypes.POINTER(Diag), c_void_p, c_void_p]
     L.mhd_mh_steps_static.argtypes = L.mhd_mh_steps.argtypes
+    L.mhd_static_reset.argtypes = [c_void_p]
+    L.mhd_stepsize_tuning.argtypes = [pp, cp, c_int32, c_void_p]
     L.mhd_cov_accumulate.argtypes = [pp, cp, c_int32, c_void_p]
     L.mhd_tempering_sweep.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p]

@@ -172,6 +172,33 @@ __device__ inline void cov_accumulate_wave(const mhd_chains_t& ch, int ib, int N
     wave_sync();
 }
 
+// Optional per-step records beside hist_m / hist_logL / hist_pred (struct mhd_diag): the five
+// counters of the chain, its per-parameter counters and its covariance matrix cov_sum / n_cov as
+// they stand after step j, the h-th recorded one.  base[] holds the chain's counters at the
+// start of the launch, d_* what the launch has added so far.  Called by the chain's first wave.
+__device__ inline void record_diag(const mhd_diag_t& dg, const mhd_chains_t& ch, int B, int ib,
+                                   int NP, size_t h, const long long* base, int d_acc, int d_rej,
+                                   int d_bnd, int d_fm, int lane)
+{
+    if (dg.hist_counters && lane < 5) {
+        const int d = lane == 0 ? d_acc : (lane == 1 ? d_rej : (lane == 2 ? d_bnd : (lane == 4 ? d_fm : 0)));
+        dg.hist_counters[(h * B + ib) * 5 + lane] = base[lane] + (long long)d;
+    }
+    if (dg.hist_counters_ind && ch.counters_ind) {
+        wave_sync();  // (the per-parameter counters are updated in place by lane 0)
+        const int64_t* ci = ch.counters_ind + (size_t)ib * NP * 5;
+        int64_t* out = dg.hist_counters_ind + (h * B + ib) * (size_t)NP * 5;
+        for (int e = lane; e < NP * 5; e += 64) out[e] = ci[e];
+    }
+    if (dg.hist_cov && ch.cov_sum && ch.n_cov) {
+        wave_sync();
+        const double* cs = ch.cov_sum + (size_t)ib * NP * NP;
+        const long long n = ch.n_cov[ib];
+        double* out = dg.hist_cov + (h * B + ib) * (size_t)NP * NP;
+        for (int e = lane; e < NP * NP; e += 64) out[e] = n > 0 ? cs[e] / (double)n : 0.0;
+    }
+}
+
 // How a chain's curves are searched, adapted to how the predictors fare on its models:
 // level 0 = windowed predictor (predict_coarse), 1 and 2 = period-by-period predictor
 // (predict_stepwise) with 3 and 9 halvings, 3 = the wave-sequential search without prediction.
@@ -309,13 +336,14 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     mhd_problem_t p, mhd_chains_t ch, int B, int S, const int32_t* idx, const double* cauchy,
     const double* u_acc, double Temp, int rotate, int sample_prior, uint8_t* accepted,
     int32_t* status, int hist_every, double* hist_m, double* hist_logL, double* hist_pred,
-    unsigned long long* n_evals, int search)
+    mhd_diag_t dg, unsigned long long* n_evals, int search)
 {
     LayerTable& T = g_T;
     if ((threadIdx.x & 63) == 0) {
         g_PS.prof_slot = (int)blockIdx.x;
         g_PS.abort = 0;
     }
+    __shared__ long long cbase[5];  // the chain's counters when the launch starts
     __shared__ double m[MAXNP];     // current parameters
     __shared__ double mn[MAXNP];    // normalised current parameters
     __shared__ double test[MAXNP];  // proposal
@@ -340,6 +368,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
         wid[lane] = ch.width[(size_t)ib * NP + lane];
         hlim[lane] = (float)HINT_SECANT_CAUCHY;
     }
+    if (lane < 5) cbase[lane] = ch.counters[(size_t)ib * 5 + lane];
     for (int k = lane; k < P; k += 64) t[k] = p.periods[k];
     for (int k = lane; k < ND; k += 64) pred[k] = ch.pred[(size_t)ib * ND + k];
     double logL = ch.logL[ib];
@@ -425,6 +454,8 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
             if (hist_logL && lane == 0) hist_logL[h * B + ib] = logL;
             if (hist_pred)
                 for (int k = lane; k < ND; k += 64) hist_pred[(h * B + ib) * ND + k] = pred[k];
+            record_diag(dg, ch, B, ib, NP, h, cbase, (int)c_acc, (int)c_rej, (int)c_bnd, (int)c_fm,
+                        lane);
         }
     }
 
@@ -491,6 +522,24 @@ __global__ __launch_bounds__(64) void tempering_sweep_kernel(const double* logL,
     }
 }
 
+// Model.stepsize_tuning (src/inversion/model.py:538-556) for every chain: one thread per
+// (chain, parameter).  The acceptance rate is n_acc / (n_acc + n_rej) once a proposal has been
+// rejected and 0 before (the reference refreshes its rates only while n_rej > 0, :483, :520);
+// above 0.4 the proposal width grows by half, in (0, 0.2) it is halved.
+__global__ __launch_bounds__(256) void stepsize_tuning_kernel(mhd_chains_t ch, int B, int NP)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * NP) return;
+    const int ib = e / NP;
+    const int64_t* c = ch.counters_ind ? ch.counters_ind + (size_t)e * 5 : ch.counters + (size_t)ib * 5;
+    const long long n_acc = c[0], n_rej = c[1];
+    const double rate = n_rej > 0 ? (double)n_acc / (double)(n_acc + n_rej) : 0.0;
+    double w = ch.width[e];
+    if (rate > 0.4) w = w * 1.5;
+    if (rate > 0.0 && rate < 0.2) w = w * 0.5;
+    ch.width[e] = w;
+}
+
 // ---- cost-aware launch schedule ---------------------------------------------
 // mhd_chains_t.sched, kept between calls: what a step of each chain cost last time (ticks of
 // the 100 MHz clock, scaled to one candidate in flight; 0 = not known yet), and what the next
@@ -499,6 +548,7 @@ __global__ __launch_bounds__(64) void tempering_sweep_kernel(const double* logL,
 // chains at its tail run with one candidate, all others with two, so a launch keeps at most two
 // waves per chain on average and the expensive chains finish closer to the others.
 constexpr int SCHED_MAX_CHAINS = 4096;  // one workgroup sorts them in LDS
+constexpr int SCHED_MIN_CHAINS = 64;    // fewer chains leave the GPU empty however they are ordered
 // a chain gets four candidates when with two it is expected to take longer than this fraction of
 // the time of the most expensive chain with four (the estimates are some 10 % uncertain)
 #ifndef SCHED_MARGIN
@@ -713,10 +763,11 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     mhd_problem_t p, mhd_chains_t ch, int B, int S, const int32_t* idx, const double* cauchy,
     const double* u_acc, double Temp, int rotate, uint8_t* accepted, int32_t* status,
-    int hist_every, double* hist_m, double* hist_logL, double* hist_pred,
+    int hist_every, double* hist_m, double* hist_logL, double* hist_pred, mhd_diag_t dg,
     unsigned long long* n_evals, int search, int scheduled)
 {
     constexpr int NG = (NW == 2) ? 2 : 1;  // chains a workgroup can hold
+    __shared__ long long cbase_[NG][5];    // the chain's counters when the launch starts
     __shared__ double lo[MAXNP], hi[MAXNP], rg[MAXNP];
     __shared__ double t[MAXP];
     __shared__ double m_[NG][MAXNP];    // current parameters
@@ -797,6 +848,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             hlim[lane] = (float)HINT_SECANT_CAUCHY;
         }
         for (int k = lane; k < ND; k += 64) pred[k] = ch.pred[(size_t)ib * ND + k];
+        if (lane < 5) cbase_[g][lane] = ch.counters[(size_t)ib * 5 + lane];
     }
     double logL = uniform_value(ch.logL[ib]);
     const double beta = uniform_value(ch.beta ? ch.beta[ib] : 1.0);
@@ -895,6 +947,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             if (hist_logL && lane == 0) hist_logL[h * B + ib] = logL;
             if (hist_pred)
                 for (int k = lane; k < ND; k += 64) hist_pred[(h * B + ib) * ND + k] = pred[k];
+            record_diag(dg, ch, B, ib, NP, h, cbase_[g], c_acc, c_rej, c_bnd, c_fm, lane);
         }
     };
     // the start of step j: update_covariance_matrix sees the state the step starts from
@@ -1238,8 +1291,10 @@ struct DeviceState {
     int cus = 0;
     void* scratch = nullptr;              // this device's copy of `scratch` (mhd_mh_steps_static)
     int scratch_B = -1;                   // what the scratch was last laid out for: chains ...
+                                          // (SCRATCH_FRESH: cleared by mhd_static_reset)
     const void* scratch_owner = nullptr;  // ... and whose (mhd_chains_t.m)
 };
+constexpr int SCRATCH_FRESH = -2;
 constexpr int MAX_DEVICES = 64;
 DeviceState g_dev[MAX_DEVICES];
 
@@ -1419,28 +1474,25 @@ static int check_chains(const mhd_chains_t* ch, int rotate, const mhd_problem_t*
     return MHD_OK;
 }
 
-// mhd_mh_steps for checked arguments.  create_state: whether the per-device state may be set up
-// here when mhd_init() has not been called for the device.
-static int mh_steps_launch(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
-                           int32_t n_steps, const int32_t* idx, const double* cauchy,
-                           const double* u_acc, double T, int32_t rotate, int32_t sample_prior,
-                           uint8_t* accepted, int32_t* status, int32_t hist_every, double* hist_m,
-                           double* hist_logL, double* hist_pred, uint64_t* n_evals,
-                           hipStream_t s, bool create_state)
+// The launches of one mhd_mh_steps call, for checked arguments.  sd: the per-device state when
+// the call may use the launch schedule (then sd->mu is held by the caller: the fork / join events
+// are shared by the callers of a device, one call enqueues at a time), else nullptr.
+static int mh_steps_enqueue(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
+                            int32_t n_steps, const int32_t* idx, const double* cauchy,
+                            const double* u_acc, double T, int32_t rotate, int32_t sample_prior,
+                            uint8_t* accepted, int32_t* status, int32_t hist_every, double* hist_m,
+                            double* hist_logL, double* hist_pred, const mhd_diag_t& dg,
+                            uint64_t* n_evals, hipStream_t s, DeviceState* sd)
 {
     unsigned long long* ne = (unsigned long long*)n_evals;
     const int search = prob->search ? prob->search : 2;
     const int candidates = prob->candidates ? prob->candidates : 2;
-    if (candidates == 2 && !sample_prior && chains->sched && B >= 64 && B <= SCHED_MAX_CHAINS) {
+    if (sd) {
         // the most expensive chains with four candidates (first, so that they are resident when
         // the others fill the GPU), the others beside them on a second stream
-        DeviceState* sd = device_state(-1, create_state);
-        if (!sd) return MHD_EHIP;
         const int slots = sd->cus * 8;  // two waves of these kernels per SIMD
         // (a short call is one launch, see SCHED_MIN_STEPS)
         const int phases = n_steps >= SCHED_PHASES_MIN_STEPS ? SCHED_PHASES : 1;
-        // the events are shared by the callers of this device: one call enqueues at a time
-        std::lock_guard<std::mutex> lock(sd->mu);
         for (int phase = 0; phase < phases; ++phase) {
             hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, chains->sched, B,
                                n_steps, phase, phases, slots);
@@ -1450,11 +1502,11 @@ static int mh_steps_launch(const mhd_problem_t* prob, const mhd_chains_t* chains
             hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(sched_cap4(B, phase)), dim3(256),
                                4 * WAVE_LDS_BYTES, s, *prob, *chains, B, n_steps, idx, cauchy,
                                u_acc, T, rotate, accepted, status, hist_every, hist_m, hist_logL,
-                               hist_pred, ne, search, 1);
+                               hist_pred, dg, ne, search, 1);
             hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES,
                                sd->stream, *prob, *chains, B, n_steps, idx, cauchy, u_acc, T,
                                rotate, accepted, status, hist_every, hist_m, hist_logL, hist_pred,
-                               ne, search, 1);
+                               dg, ne, search, 1);
             e = hipEventRecord(sd->join, sd->stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(s, sd->join, 0);
             if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps join");
@@ -1462,79 +1514,137 @@ static int mh_steps_launch(const mhd_problem_t* prob, const mhd_chains_t* chains
     } else if (candidates == 2 && !sample_prior) {
         hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES, s,
                            *prob, *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, accepted,
-                           status, hist_every, hist_m, hist_logL, hist_pred, ne, search, 0);
+                           status, hist_every, hist_m, hist_logL, hist_pred, dg, ne, search, 0);
     } else if (candidates == 4 && !sample_prior) {
         hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(B), dim3(256), 4 * WAVE_LDS_BYTES, s,
                            *prob, *chains, B, n_steps, idx, cauchy, u_acc, T, rotate, accepted,
-                           status, hist_every, hist_m, hist_logL, hist_pred, ne, search, 0);
+                           status, hist_every, hist_m, hist_logL, hist_pred, dg, ne, search, 0);
     } else {
         hipLaunchKernelGGL(mh_steps_kernel, dim3(B), dim3(64), WAVE_LDS_BYTES, s, *prob, *chains,
                            B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior, accepted,
-                           status, hist_every, hist_m, hist_logL, hist_pred, ne, search);
+                           status, hist_every, hist_m, hist_logL, hist_pred, dg, ne, search);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_mh_steps launch");
 }
 
+// Whether a call with these arguments uses the launch schedule (mhd_chains_t.sched).
+static bool uses_schedule(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
+                          int32_t sample_prior)
+{
+    const int candidates = prob->candidates ? prob->candidates : 2;
+    return candidates == 2 && !sample_prior && chains->sched && B >= SCHED_MIN_CHAINS &&
+           B <= SCHED_MAX_CHAINS;
+}
+
 // 0: go on; 1: nothing to do; < 0: refused
 static int mh_steps_check(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
                           int32_t n_steps, const int32_t* idx, const double* cauchy,
-                          const double* u_acc, double T, int32_t rotate, int32_t hist_every)
+                          const double* u_acc, double T, int32_t rotate, int32_t hist_every,
+                          const mhd_diag_t* diag)
 {
     if (int rc = check_problem(prob, true)) return rc;
     if (int rc = check_chains(chains, rotate, prob)) return rc;
     if (B < 0 || n_steps < 0 || hist_every < 0) return fail(MHD_EINVAL, "negative size");
     if (!(T > 0.0)) return fail(MHD_EINVAL, "T must be positive");
+    if (diag && diag->hist_counters_ind && !chains->counters_ind)
+        return fail(MHD_EINVAL, "hist_counters_ind needs counters_ind");
+    if (diag && diag->hist_cov && (!chains->cov_sum || !chains->n_cov))
+        return fail(MHD_EINVAL, "hist_cov needs cov_sum and n_cov");
     if (B == 0 || n_steps == 0) return 1;  // (no steps may come with NULL draw arrays)
     if (!idx || !cauchy || !u_acc) return fail(MHD_EINVAL, "draw array is NULL");
     return 0;
 }
 
+int mhd_sched_min_steps(void) { return SCHED_PHASES_MIN_STEPS; }
+
 int mhd_mh_steps(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
                  int32_t n_steps, const int32_t* idx, const double* cauchy, const double* u_acc,
                  double T, int32_t rotate, int32_t sample_prior, uint8_t* accepted,
                  int32_t* status, int32_t hist_every, double* hist_m, double* hist_logL,
-                 double* hist_pred, uint64_t* n_evals, void* stream)
+                 double* hist_pred, const mhd_diag_t* diag, uint64_t* n_evals, void* stream)
 {
     const int rc = mh_steps_check(prob, chains, B, n_steps, idx, cauchy, u_acc, T, rotate,
-                                  hist_every);
+                                  hist_every, diag);
     if (rc) return rc < 0 ? rc : MHD_OK;
-    return mh_steps_launch(prob, chains, B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior,
-                           accepted, status, hist_every, hist_m, hist_logL, hist_pred, n_evals,
-                           (hipStream_t)stream, true);
+    const mhd_diag_t dg = diag ? *diag : mhd_diag_t{nullptr, nullptr, nullptr};
+    if (!uses_schedule(prob, chains, B, sample_prior))
+        return mh_steps_enqueue(prob, chains, B, n_steps, idx, cauchy, u_acc, T, rotate,
+                                sample_prior, accepted, status, hist_every, hist_m, hist_logL,
+                                hist_pred, dg, n_evals, (hipStream_t)stream, nullptr);
+    DeviceState* sd = device_state(-1, true);
+    if (!sd) return MHD_EHIP;
+    std::lock_guard<std::mutex> lock(sd->mu);
+    return mh_steps_enqueue(prob, chains, B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior,
+                            accepted, status, hist_every, hist_m, hist_logL, hist_pred, dg,
+                            n_evals, (hipStream_t)stream, sd);
+}
+
+int mhd_static_reset(void* stream)
+{
+    DeviceState* sd = device_state(-1, false);
+    if (!sd) return MHD_EINVAL;
+    std::lock_guard<std::mutex> lock(sd->mu);
+    const hipError_t e = hipMemsetAsync(sd->scratch, 0, STATIC_SCRATCH_BYTES, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "mhd_static_reset memset");
+    sd->scratch_B = SCRATCH_FRESH;
+    sd->scratch_owner = nullptr;
+    return MHD_OK;
 }
 
 int mhd_mh_steps_static(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
                         int32_t n_steps, const int32_t* idx, const double* cauchy,
                         const double* u_acc, double T, int32_t rotate, int32_t sample_prior,
                         uint8_t* accepted, int32_t* status, int32_t hist_every, double* hist_m,
-                        double* hist_logL, double* hist_pred, uint64_t* n_evals, void* stream)
+                        double* hist_logL, double* hist_pred, const mhd_diag_t* diag,
+                        uint64_t* n_evals, void* stream)
 {
     const int rc = mh_steps_check(prob, chains, B, n_steps, idx, cauchy, u_acc, T, rotate,
-                                  hist_every);
+                                  hist_every, diag);
     if (rc) return rc < 0 ? rc : MHD_OK;
     if (B > STATIC_MAX_CHAINS)
         return fail(MHD_EINVAL, "mhd_mh_steps_static: more than 4096 chains, the static scratch "
                                 "holds the launch schedule of 4096");
     DeviceState* sd = device_state(-1, false);  // made by mhd_init(); nothing is created here
     if (!sd) return MHD_EINVAL;
+    const mhd_diag_t dg = diag ? *diag : mhd_diag_t{nullptr, nullptr, nullptr};
     mhd_chains_t ch = *chains;
     ch.sched = sd->scratch;
-    {
-        // other chains than the last call's: their costs and search levels must not be taken
-        // for these (and the layout depends on B)
-        std::lock_guard<std::mutex> lock(sd->mu);
-        if (sd->scratch_B != B || sd->scratch_owner != (const void*)chains->m) {
-            const hipError_t e =
-                hipMemsetAsync(sd->scratch, 0, sched_bytes_of((size_t)B), (hipStream_t)stream);
-            if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps_static memset");
-            sd->scratch_B = B;
-            sd->scratch_owner = (const void*)chains->m;
-        }
+    // one call at a time per device from here to the last launch: the owner of the scratch, its
+    // clearing and the launches that use it belong together
+    std::lock_guard<std::mutex> lock(sd->mu);
+    if (sd->scratch_B == SCRATCH_FRESH) {
+        // cleared by mhd_static_reset(): whoever comes first owns it, nothing to enqueue
+        sd->scratch_B = B;
+        sd->scratch_owner = (const void*)chains->m;
+    } else if (sd->scratch_B != B || sd->scratch_owner != (const void*)chains->m) {
+        // other chains than the last call's (by the address of their parameters): their costs
+        // and search levels must not be taken for these, and the layout depends on B
+        const hipError_t e =
+            hipMemsetAsync(sd->scratch, 0, sched_bytes_of((size_t)B), (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps_static memset");
+        sd->scratch_B = B;
+        sd->scratch_owner = (const void*)chains->m;
     }
-    return mh_steps_launch(prob, &ch, B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior,
-                           accepted, status, hist_every, hist_m, hist_logL, hist_pred, n_evals,
-                           (hipStream_t)stream, false);
+    return mh_steps_enqueue(prob, &ch, B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior,
+                            accepted, status, hist_every, hist_m, hist_logL, hist_pred, dg,
+                            n_evals, (hipStream_t)stream,
+                            uses_schedule(prob, &ch, B, sample_prior) ? sd : nullptr);
+}
+
+int mhd_stepsize_tuning(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
+                        void* stream)
+{
+    if (int rc = check_problem(prob, false)) return rc;
+    if (!chains || !chains->width || !chains->counters)
+        return fail(MHD_EINVAL, "chains / width / counters is NULL");
+    if (B < 0) return fail(MHD_EINVAL, "negative batch");
+    if (B == 0) return MHD_OK;
+    const int NP = 2 * prob->n_layers + 1;
+    hipLaunchKernelGGL(stepsize_tuning_kernel, dim3((B * NP + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, *chains, B, NP);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_stepsize_tuning launch");
 }
 
 int mhd_tempering_sweep(const double* logL, double* beta, const double* u, int32_t n_temps,

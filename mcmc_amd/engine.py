@@ -61,8 +61,12 @@ class DeviceProblem:
         L.lib()
         if not torch.cuda.is_available():
             raise L.MhdError("no GPU visible: the hot path has no CPU fallback")
-        self.device = torch.device(device if device is not None else
-                                   f"cuda:{torch.cuda.current_device()}")
+        # (always with an index: "cuda" and torch.device("cuda") mean the current device)
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise L.MhdError("the hot path runs on a GPU: device must be a cuda device")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.n_layers = int(n_layers)
         self.NP = 2 * self.n_layers + 1
         self.search, self.candidates = int(search), int(candidates)
@@ -210,14 +214,17 @@ class DeviceChains:
         return status
 
     def steps(self, idx, cauchy, u_acc, T=1.0, rotate=0, sample_prior=False, hist_every=0,
-              want_flags=True, want_pred_hist=False, static_scratch=False):
+              want_flags=True, want_pred_hist=False, static_scratch=False, want_diag=False):
         """Run S = idx.shape[0] Metropolis-Hastings steps for every chain.
 
         idx [S,B] int32, cauchy [S,B], u_acc [S,B] are device tensors of host-supplied draws.
         static_scratch: through mhd_mh_steps_static (the library's static device scratch
         instead of self.sched).
         Returns dict with accepted [S,B] uint8, status [S,B] int32 and, when hist_every > 0,
-        hist_m [S//hist_every,B,NP] and hist_logL [S//hist_every,B].
+        hist_m [S//hist_every,B,NP] and hist_logL [S//hist_every,B]; with want_diag also
+        hist_counters [S//hist_every,B,5] (int64), hist_counters_ind [..,B,NP,5] when the chains
+        keep per-parameter counters, and hist_cov [..,B,NP,NP] in calls with a rotate flag
+        (struct mhd_diag).
         """
         S, B = idx.shape
         assert B == self.B and cauchy.shape == (S, B) and u_acc.shape == (S, B)
@@ -240,15 +247,35 @@ class DeviceChains:
                 hp = torch.empty((S // hist_every, B, self.prob.ND), dtype=torch.float64,
                                  device=dev)
                 out["hist_pred"] = hp
+        diag = None
+        if hist_every > 0 and want_diag:
+            n, NP = S // hist_every, self.prob.NP
+            i64 = dict(dtype=torch.int64, device=dev)
+            out["hist_counters"] = torch.empty((n, B, 5), **i64)
+            diag = L.Diag(hist_counters=out["hist_counters"].data_ptr())
+            if self.counters_ind is not None:
+                out["hist_counters_ind"] = torch.empty((n, B, NP, 5), **i64)
+                diag.hist_counters_ind = out["hist_counters_ind"].data_ptr()
+            if rotate and self.cov_sum is not None:
+                out["hist_cov"] = torch.empty((n, B, NP, NP), dtype=torch.float64, device=dev)
+                diag.hist_cov = out["hist_cov"].data_ptr()
         ch = self.struct()
         with torch.cuda.device(dev):
             entry = L.lib().mhd_mh_steps_static if static_scratch else L.lib().mhd_mh_steps
             L.check(entry(
                 self.prob.cref(self.n_layers_b), ctypes.byref(ch), B, S, _ptr(idx), _ptr(cauchy),
                 _ptr(u_acc), float(T), int(rotate), int(bool(sample_prior)), _ptr(acc),
-                _ptr(st), int(hist_every), _ptr(hm), _ptr(hl), _ptr(hp), _ptr(self.n_evals),
-                _stream(dev)))
+                _ptr(st), int(hist_every), _ptr(hm), _ptr(hl), _ptr(hp),
+                None if diag is None else ctypes.byref(diag), _ptr(self.n_evals), _stream(dev)))
         return out
+
+    def stepsize_tuning(self):
+        """Model.stepsize_tuning (src/inversion/model.py:538-556) for every chain, from the
+        counters on the device: the widths change in place, nothing waits for the device."""
+        ch = self.struct()
+        with torch.cuda.device(self.prob.device):
+            L.check(L.lib().mhd_stepsize_tuning(self.prob.cref(), ctypes.byref(ch), self.B,
+                                                _stream(self.prob.device)))
 
     def cov_accumulate(self):
         ch = self.struct()

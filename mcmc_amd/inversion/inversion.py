@@ -29,18 +29,28 @@ Differences from the reference, all deliberate:
     numbers of layers, up to model_params.n_layers; every chain keeps its count,
     there are no birth / death moves.  Rows are padded (see mhd_problem_t.n_layers_b)
     and the perturbed parameter is drawn among the chain's own.
+  * tune_stepsize (not in the reference's constructor): Model.stepsize_tuning
+    (src/inversion/model.py:538-556) is defined by the reference and its call, after
+    every step, is commented out (:257).  tune_stepsize = N applies it on the device
+    (`mhd_stepsize_tuning`) after every N-th outer step of the burn-in; None (the
+    default) never, as in the reference.
   * Results go to chunked .npz files (input-<name>.npz once, results-<name>-
     <chunk>.npz every n_chunk steps) with the reference's variable names
     (src/inversion/inversion.py:150-231) instead of a netCDF file that is re-read
-    and rewritten every chunk.  A tempered run records every replica of the
-    process together with its beta at each step (the reference keeps the
-    beta == 1 chains, :442); select with `beta == 1`.
+    and rewritten every chunk; the download and the file are made beside the
+    sampling (a copy stream and a writer thread), random_walk returns when the last
+    file is closed.  Every replica of the process is recorded together with its
+    beta at each step (the reference keeps the beta == 1 chains, :442); select
+    with `beta == 1`.  write_results=False writes nothing at all.
 Multi-GPU: when torch.distributed is initialised, every rank owns a contiguous
 block of the replicas; the only exchange is one all-gather of the per-replica
 logL per tempering sweep, after which every rank runs the same sweep on the
 same numbers and so holds the same betas.
 """
 import os
+import queue
+import threading
+import time
 
 import numpy as np
 
@@ -74,12 +84,119 @@ def ladder_layout(n_temps, n_ladders, layout):
     raise ValueError("layout must be 'ladder' or 'rung'")
 
 
+def all_gather_blocks(out, local):
+    """out[r * n:(r + 1) * n] = rank r's `local` (n values) for every rank: the one collective of
+    the sampler, used for the per-replica logL of a tempering sweep.  RCCL ("nccl") on GPUs
+    works in the order of the current stream; any other backend (gloo, in rehearsals and
+    tests) reads the memory from the host, so the stream that produces `local` is waited for
+    first."""
+    import torch
+    import torch.distributed as dist
+    if local.is_cuda and dist.get_backend() != "nccl":
+        torch.cuda.current_stream(local.device).synchronize()
+    dist.all_gather_into_tensor(out, local)
+    return out
+
+
+def rates_from_counters(cnt):
+    """The rates Inversion.store_samples keeps per step (src/inversion/inversion.py:459-487) from
+    the counters [..., 5] = n_acc, n_rej, n_bounds_err, n_physics_err, n_fm_err: each count over
+    n_acc + n_rej, and 0 until a proposal has been rejected (the reference refreshes its rates
+    only while n_rej > 0, src/inversion/model.py:483, :520)."""
+    cnt = np.asarray(cnt, dtype=np.float64)
+    tot = cnt[..., 0] + cnt[..., 1]
+    live = cnt[..., 1] > 0
+    safe = np.where(live, tot, 1.0)
+    return {name: np.where(live, cnt[..., k] / safe, 0.0)
+            for name, k in (("acc_rate", 0), ("bounds_err", 2), ("physics_err", 3), ("fm_err", 4))}
+
+
+class _ChunkWriter:
+    """Writes result chunks beside the sampling: the device arrays of a chunk are copied into
+    pinned host memory on a stream of their own, and a worker thread waits for that copy, turns
+    the counters into rates and writes the .npz file."""
+
+    def __init__(self, device):
+        import torch
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        self.jobs = queue.Queue()
+        self.error = None
+        self.thread = threading.Thread(target=self._work, daemon=True)
+        self.thread.start()
+
+    def submit(self, path, pieces, extras):
+        """pieces: name -> list of device tensors (concatenated along axis 0 in the file);
+        extras: name -> numpy value."""
+        import torch
+        if self.error is not None:
+            self.flush()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        self.stream.wait_event(ready)
+        host = {}
+        with torch.cuda.stream(self.stream):
+            for name, parts in pieces.items():
+                host[name] = []
+                for t in parts:
+                    t.record_stream(self.stream)
+                    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    h.copy_(t, non_blocking=True)
+                    host[name].append(h)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self.jobs.put((path, host, extras, done))
+
+    def _work(self):
+        while True:
+            job = self.jobs.get()
+            try:
+                if job is None:
+                    return
+                if self.error is None:
+                    path, host, extras, done = job
+                    done.synchronize()
+                    out = {k: np.concatenate([h.numpy() for h in v], axis=0)
+                           for k, v in host.items()}
+                    out.update(extras)
+                    _finish_on_host(out)
+                    np.savez(path, **out)
+            except BaseException as e:  # reported by flush() on the sampling thread
+                self.error = e
+            finally:
+                self.jobs.task_done()
+
+    def flush(self):
+        self.jobs.join()
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+    def close(self):
+        self.jobs.put(None)
+        self.thread.join()
+
+
+def _finish_on_host(out):
+    """Counters of a chunk into the reference's rates; per-segment widths into per-step ones."""
+    for key in ("counters", "counters_ind"):
+        if key in out:
+            cnt = out.pop(key)
+            if key == "counters" and "counters_ind" in out:
+                continue  # (individual_acceptance: the per-parameter rates are the record)
+            out.update(rates_from_counters(cnt))
+    if "width_seg" in out:
+        reps = out.pop("width_reps")
+        out["proposal_width"] = np.repeat(out.pop("width_seg"), reps, axis=0)
+
+
 class Inversion:
     def __init__(self, data, model_params, noise_dist, noise_params, n_burn, n_chunk, n_mcmc,
                  n_cov_chunk=200, n_thin=1, n_chains=1, individual_acceptance=False,
                  beta_spacing_factor=None, out_filename=None, set_starting_model=False,
                  out_dir="./results/inversion/", reference_betas=False, swap_seed=0,
-                 n_temps=None, layout="ladder", layer_counts=None):
+                 n_temps=None, layout="ladder", layer_counts=None, tune_stepsize=None,
+                 write_results=True, record_diagnostics="step", async_sink=True):
         import torch.distributed as dist
         self.data = data
         self.n_burn, self.n_chunk, self.n_mcmc, self.n_thin = n_burn, n_chunk, n_mcmc, n_thin
@@ -89,6 +206,13 @@ class Inversion:
         self.noise_dist, self.noise_params = noise_dist, noise_params
         self.n_chains = n_chains
         self.reference_betas = reference_betas
+        if tune_stepsize is not None and int(tune_stepsize) < 1:
+            raise ValueError("tune_stepsize: a number of outer steps, or None")
+        self.tune_stepsize = None if tune_stepsize is None else int(tune_stepsize)
+        if record_diagnostics not in ("chunk", "step", "full"):
+            raise ValueError("record_diagnostics must be 'chunk', 'step' or 'full'")
+        self.record_diagnostics = record_diagnostics
+        self.async_sink = bool(async_sink)
         # temperature ladders: the reference's flat ladder over all chains, or n_chains ladders
         if n_temps is None:
             self.n_temps, self.n_ladders = n_chains, 1
@@ -112,13 +236,24 @@ class Inversion:
                 raise ValueError("layer_counts: one count in 1..n_layers per replica")
             self.layer_counts = lc[self._lo:self._lo + self.n_local].copy()
         self.out_dir = out_dir
-        # results are written only when the caller names a file (the reference makes up a name
-        # from the clock, src/inversion/inversion.py:62-66; with several ranks those would differ)
-        self.out_filename = out_filename if out_filename else None
+        # Without a name the reference makes one up from the clock
+        # (src/inversion/inversion.py:83-86); with several ranks the name has to be the same on
+        # all of them, so rank 0's clock is the one that counts.  write_results=False: no files.
+        self.out_filename = None
+        if write_results:
+            self.out_filename = out_filename if out_filename else self._clock_name()
+        self._writer = None
         self.initialize_chains(model_params, noise_dist, noise_params, n_cov_chunk,
                                individual_acceptance, beta_spacing_factor, set_starting_model)
-        if out_filename is not None and self.rank == 0:
+        if self.out_filename is not None and self.rank == 0:
             self.define_input_dataset(data, model_params, noise_dist, noise_params)
+
+    def _clock_name(self):
+        import torch.distributed as dist
+        name = [str(int(time.time()))]
+        if self.world > 1:
+            dist.broadcast_object_list(name, src=0)
+        return name[0]
 
     # ------------------------------------------------------------------ set-up
     def get_betas(self, beta_spacing_factor, n_temps=None):
@@ -235,17 +370,46 @@ class Inversion:
         np.savez(path, **out)
 
     def _write_chunk(self, chunk, rec):
+        """One results file from the records of a chunk (name -> list of device tensors or
+        numpy arrays).  The file's existence is checked here; the download and the writing go
+        on beside the sampling (see _ChunkWriter) unless async_sink is off."""
+        import torch
         if self.out_filename is None or not rec:
             return
         path = self._path("results", chunk)
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         if os.path.isfile(path):
             raise PermissionError("File already exists.")
-        np.savez(path, **rec)
+        extras = {"chain": self._lo + np.arange(self.n_local), "rank": self.rank}
+        pieces = {}
+        for k, v in rec.items():
+            if isinstance(v, np.ndarray):
+                extras[k] = v
+            elif all(torch.is_tensor(x) for x in v):
+                pieces[k] = list(v)
+            else:
+                extras[k] = np.concatenate([x.cpu().numpy() if torch.is_tensor(x)
+                                            else np.asarray(x) for x in v], axis=0)
+        if not pieces or not any(t.is_cuda for v in pieces.values() for t in v):
+            out = {k: np.concatenate([t.numpy() for t in v], axis=0) for k, v in pieces.items()}
+            out.update(extras)
+            _finish_on_host(out)
+            np.savez(path, **out)
+            return
+        if self._writer is None:
+            self._writer = _ChunkWriter(self.prob.device)
+        self._writer.submit(path, pieces, extras)
+        if not getattr(self, "async_sink", True):
+            self._writer.flush()
+
+    def flush_results(self):
+        """Waits until every results file handed to the writer is on disk (random_walk does)."""
+        if self._writer is not None:
+            self._writer.flush()
 
     # ------------------------------------------------------------------ stepping
     def step_segment(self, idx, cauchy, u_acc, rotate=0, sample_prior=False, hist_every=0,
-                     want_pred_hist=False, T=1.0):
+                     want_pred_hist=False, T=1.0, want_diag=False):
         """Run idx.shape[0] MH steps for every local chain on supplied draws (numpy arrays, or
         device tensors, which are used as they are)."""
         import torch
@@ -258,7 +422,7 @@ class Inversion:
         return self.state.steps(t(idx, torch.int32), t(cauchy, torch.float64),
                                 t(u_acc, torch.float64), T=T, rotate=rotate,
                                 sample_prior=sample_prior, hist_every=hist_every,
-                                want_pred_hist=want_pred_hist)
+                                want_pred_hist=want_pred_hist, want_diag=want_diag)
 
     def _draws(self, S):
         NP = self.model_params.n_model_params
@@ -285,6 +449,12 @@ class Inversion:
     def _is_refresh(self, s):
         return s >= self.n_burn + self.n_cov_chunk + 2 and s % self.n_cov_chunk == 0
 
+    def _is_tuned_after(self, s):
+        """Whether Model.stepsize_tuning follows outer step s (a step of the burn-in whose
+        number, counted from one, is a multiple of tune_stepsize)."""
+        return (self.tune_stepsize is not None and s < self.n_burn
+                and (s + 1) % self.tune_stepsize == 0)
+
     def _run_segment(self, step, seg, idx, cz, xi, rotate_params, sample_prior):
         """Outer steps step..step+seg-1 (seg * n_thin MH steps on the draws given, which begin at
         this segment); at most the first of them refreshes the rotation matrix.  Returns the
@@ -296,6 +466,7 @@ class Inversion:
             rot = L.ROT_ACCUMULATE | (0 if step < self.n_burn else L.ROT_FRAME)
         lo = 0
         outs = []
+        diag = getattr(self, "record_diagnostics", "chunk") != "chunk"
         if rotate_params and self._is_refresh(step):
             # covariance first, then the new rotation, then the proposal of this
             # thin-iteration (src/inversion/model.py:183-193)
@@ -303,13 +474,14 @@ class Inversion:
             self._refresh_rotation()
             out0 = self.step_segment(idx[:1], cz[:1], xi[:1], rotate=L.ROT_FRAME,
                                      sample_prior=sample_prior,
-                                     hist_every=1 if nt == 1 else 0, want_pred_hist=nt == 1)
+                                     hist_every=1 if nt == 1 else 0, want_pred_hist=nt == 1,
+                                     want_diag=diag and nt == 1)
             lo = 1
             if nt == 1:
                 outs.append(out0)
         if S > lo:
             # history after every n_thin-th step of the segment
-            kw = dict(rotate=rot, sample_prior=sample_prior, want_pred_hist=True)
+            kw = dict(rotate=rot, sample_prior=sample_prior, want_pred_hist=True, want_diag=diag)
             if lo == 0:
                 outs.append(self.step_segment(idx[:S], cz[:S], xi[:S], hist_every=nt, **kw))
             elif nt == 1:
@@ -321,18 +493,49 @@ class Inversion:
                 if S > nt:
                     outs.append(self.step_segment(idx[nt:S], cz[nt:S], xi[nt:S], hist_every=nt,
                                                   **kw))
+        # the width every record of this segment was made with (it changes between segments
+        # only: at a rotation refresh, before the segment's first step, and by the tuning)
+        for o in outs:
+            if "hist_m" in o:
+                o["width"] = self.state.width.clone()
         return outs
+
+    def _tune_after(self, step, rec):
+        """Model.stepsize_tuning after outer step `step` (the last of a segment), on the device;
+        the step's record shows the widths as the tuning left them, as a record made at the end
+        of the reference's perturb_params would."""
+        if not self._is_tuned_after(step):
+            return
+        self.state.stepsize_tuning()
+        if rec.get("width_seg"):
+            n = rec["width_reps"][-1]
+            if n > 1:
+                rec["width_reps"][-1] = n - 1
+                rec["width_seg"].append(self.state.width.clone()[None])
+                rec["width_reps"].append(1)
+            else:
+                rec["width_seg"][-1] = self.state.width.clone()[None]
 
     def random_walk(self, model_params, proposal_distribution, sample_prior=False,
                     rotate_params=False):
         """The main loop for n_mcmc steps (src/inversion/inversion.py:367-429)."""
         if proposal_distribution != "cauchy":
-            raise NotImplementedError("only the 'cauchy' proposal is mirrored")
-        if self.tempering:
-            return self._random_walk_tempered(rotate_params, sample_prior)
+            raise NotImplementedError(
+                "only the 'cauchy' proposal is mirrored; the reference's 'uniform' branch adds a "
+                "physical bound to a normalised value (src/inversion/model.py:207)")
+        try:
+            if self.tempering:
+                self._random_walk_tempered(rotate_params, sample_prior)
+            else:
+                self._random_walk_plain(rotate_params, sample_prior)
+        finally:
+            self.flush_results()
+        self._sync_host()
+
+    def _random_walk_plain(self, rotate_params, sample_prior):
         def segment(step):
-            # a segment ends at a chunk boundary and before a step on which the rotation matrix
-            # is refreshed
+            # a segment ends at a chunk boundary, before a step on which the rotation matrix is
+            # refreshed, and after a step that the step-size tuning follows
             seg = min(self.n_chunk - step % self.n_chunk, self.n_mcmc - step)
             if rotate_params:
                 nxt = next((s for s in range(step + 1, step + seg) if self._is_refresh(s)), None)
@@ -340,6 +543,8 @@ class Inversion:
                     seg = nxt - step
                 if step < self.n_burn:
                     seg = min(seg, self.n_burn - step)
+            if self.tune_stepsize is not None and step < self.n_burn:
+                seg = min(seg, self.tune_stepsize - step % self.tune_stepsize)
             return seg
 
         rec = {}
@@ -350,6 +555,7 @@ class Inversion:
             outs = self._run_segment(step, seg, *draws, rotate_params, sample_prior)
             self._store(rec, outs)
             step += seg
+            self._tune_after(step - 1, rec)
             self._n_step = step
             # the draws of the next segment (the same sequence of np.random calls as ever) while
             # the device works on this one: the launches above do not wait for it
@@ -360,7 +566,6 @@ class Inversion:
                     self._write_chunk((step - 1) // self.n_chunk, self._finish(rec))
                 rec = {}
             seg = seg_next
-        self._sync_host()
 
     def _random_walk_tempered(self, rotate_params, sample_prior):
         """Tempered run: per outer step n_thin MH steps of every replica, the all-gather of logL
@@ -385,15 +590,15 @@ class Inversion:
                 a, b = j * nt, (j + 1) * nt
                 outs = self._run_segment(step + j, 1, idx[a:b], cz[a:b], xi[a:b], rotate_params,
                                          sample_prior)
+                self._store(rec, outs)
+                self._tune_after(step + j, rec)
                 self.perform_tempering_swap(u_swap[j])
                 beta_hist[j] = self.state.beta
-                self._store(rec, outs)
             rec["beta"] = [beta_hist]
             step += n_outer
             self._n_step = step
             if self.out_filename is not None:
                 self._write_chunk((step - 1) // self.n_chunk, self._finish(rec))
-        self._sync_host()
 
     def _store(self, rec, outs):
         """Per-step records (src/inversion/inversion.py:431-487) of every chain of this process;
@@ -405,35 +610,41 @@ class Inversion:
             rec.setdefault("logL", []).append(o["hist_logL"])
             if "hist_pred" in o:
                 rec.setdefault("data_pred", []).append(o["hist_pred"])
+            if "hist_counters" in o:
+                rec.setdefault("counters", []).append(o["hist_counters"])
+                rec.setdefault("width_seg", []).append(o["width"][None])
+                rec.setdefault("width_reps", []).append(o["hist_m"].shape[0])
+            if "hist_counters_ind" in o:
+                rec.setdefault("counters_ind", []).append(o["hist_counters_ind"])
+            if "hist_cov" in o and getattr(self, "record_diagnostics", "chunk") == "full":
+                rec.setdefault("cov_mat", []).append(o["hist_cov"])
 
     def _finish(self, rec):
-        import torch
-        out = {}
-        for k, v in rec.items():
-            v = [x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x) for x in v]
-            out[k] = np.concatenate(v, axis=0)
-        out["chain"] = self._lo + np.arange(self.n_local)
-        cnt = self.state.counters.cpu().numpy()
-        tot = np.maximum(cnt[:, 0] + cnt[:, 1], 1)
-        out["acc_rate"] = cnt[:, 0] / tot
-        out["bounds_err"] = cnt[:, 2] / tot
-        out["physics_err"] = cnt[:, 3] / tot
-        out["fm_err"] = cnt[:, 4] / tot
-        out["proposal_width"] = self.state.width.cpu().numpy()
-        out["cov_mat"] = (self.state.cov_sum /
-                          self.state.n_cov.clamp(min=1)[:, None, None].double()).cpu().numpy()
-        out["rank"] = self.rank
+        """The records of a chunk as they go to the writer: per-step arrays (lists of device
+        tensors) and, for what is kept once per chunk, the values at the chunk's end.
+        record_diagnostics "step": acc_rate, bounds_err, physics_err, fm_err and proposal_width
+        after every step, cov_mat at the end of the chunk; "full": cov_mat after every step as
+        well (in runs with rotate_params); "chunk": all of them at the end only."""
+        out = dict(rec)
+        if "width_reps" in out:
+            out["width_reps"] = [np.asarray(out["width_reps"], dtype=np.int64)]
+        if "counters" not in out:
+            key = "counters_ind" if self.state.counters_ind is not None else "counters"
+            out[key] = [(self.state.counters_ind if key == "counters_ind"
+                         else self.state.counters).clone()]
+            out["proposal_width"] = [self.state.width.clone()]
+        if "cov_mat" not in out:
+            out["cov_mat"] = [self.state.cov_sum /
+                              self.state.n_cov.clamp(min=1)[:, None, None].double()]
         return out
 
     # ------------------------------------------------------------------ tempering
     def gather_logL(self):
         """logL of all replicas on the device: the one collective of the sampler (an all-gather
         of n_local float64 per rank; RCCL on GPUs)."""
-        import torch.distributed as dist
         if self.world == 1:
             return self.state.logL
-        dist.all_gather_into_tensor(self.logL_all, self.state.logL)
-        return self.logL_all
+        return all_gather_blocks(self.logL_all, self.state.logL)
 
     def perform_tempering_swap(self, u=None):
         """Exchange move between temperature neighbours of every ladder
@@ -442,7 +653,7 @@ class Inversion:
         Every rank runs the sweep over all ladders from the gathered logL and the shared
         uniforms u [n_ladders, n_temps-1] (drawn from swap_rng when not given), so the betas
         stay identical everywhere; betas are swapped, states never move.  Nothing here waits
-        for the device.
+        for the device (with RCCL; a host-side backend waits for the stream).
         """
         import torch
         from ..engine import tempering_sweep
@@ -451,19 +662,3 @@ class Inversion:
                                 device=self.prob.device)
         tempering_sweep(self.gather_logL(), self.beta_all, u.contiguous(), self.n_temps,
                         self.n_ladders, self.rung_stride, self.ladder_stride, self.swap_counts)
-
-
-def gather_chain_values(local, n_total, world):
-    """All-gather of a per-chain float64 vector (a torch tensor) over the ranks to the host;
-    every rank owns a contiguous block of n_total / world chains.  RCCL ("nccl") on GPUs, gloo
-    on the host."""
-    import torch
-    import torch.distributed as dist
-    if world == 1:
-        return local.detach().cpu().numpy()
-    local = local.detach().contiguous()
-    if dist.get_backend() == "gloo":
-        local = local.cpu()
-    full = torch.empty(n_total, dtype=torch.float64, device=local.device)
-    dist.all_gather_into_tensor(full, local)
-    return full.cpu().numpy()

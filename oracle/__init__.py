@@ -222,6 +222,24 @@ def cov_accumulate(state):
                              state.n_cov.ctypes.data_as(_lp), _d(state.bounds), state.B, state.NP)
 
 
+def stepsize_tuning(width, n_acc, n_rej):
+    """Model.stepsize_tuning (src/inversion/model.py:538-556) for a batch: width [B,NP];
+    n_acc, n_rej [B] (one rate per chain: every width of the chain is scaled alike, as the
+    reference's boolean scalar index does) or [B,NP] (individual_acceptance).  The rate is
+    n_acc / (n_acc + n_rej) once n_rej > 0 and 0 before (:483, :520).  Returns the new widths."""
+    width = np.array(width, dtype=float)
+    n_acc, n_rej = np.asarray(n_acc, dtype=float), np.asarray(n_rej, dtype=float)
+    rate = np.where(n_rej > 0, n_acc / np.maximum(n_acc + n_rej, 1.0), 0.0)
+    if rate.ndim == 1:
+        rate = rate[:, None]
+    rate = np.broadcast_to(rate, width.shape)
+    high = rate > 0.4
+    low = (rate > 0) & (rate < 0.2)
+    width[high] = width[high] * 1.5
+    width[low] = width[low] * 0.5
+    return width
+
+
 def set_threads(n):
     """Threads orc_mh_step spreads the chains over (1 = scalar)."""
     lib().orc_set_threads(int(n))

@@ -21,7 +21,7 @@ for label, files in (("no result files", False), ("result files (.npz per chunk)
         np.random.seed(1)
         with tempfile.TemporaryDirectory() as tmp:
             inv = Inversion(data, mp, "normal", {"std": STD}, n_burn=0, n_chunk=50, n_mcmc=n_mcmc, n_thin=10,
-                            n_chains=1024, n_temps=1, out_filename="e2e" if files else None, out_dir=tmp + "/")
+                            n_chains=1024, n_temps=1, out_filename="e2e", write_results=bool(files), out_dir=tmp + "/")
             torch.cuda.synchronize(); t0 = time.perf_counter()
             inv.random_walk(mp, "cauchy")
             torch.cuda.synchronize(); dt = time.perf_counter() - t0

@@ -160,7 +160,7 @@ def test_ellipticity_params_through_inversion(oracle, tmp_path):
     data.model_true = true_m
     np.random.seed(3)
     inv = Inversion(data, mp, "normal", noise, n_burn=0, n_chunk=40, n_mcmc=40, n_thin=2,
-                    n_chains=4, n_temps=1, set_starting_model=True, out_filename=None)
+                    n_chains=4, n_temps=1, set_starting_model=True, write_results=False)
     drawn = []
     orig = inv._draws
 
@@ -204,7 +204,7 @@ def test_joint_inversion_with_burn_in_rotation(oracle):
     np.random.seed(5)
     inv = Inversion(data, mp, "normal", noise, n_burn=n_burn, n_chunk=45, n_mcmc=n_mcmc,
                     n_cov_chunk=n_cov_chunk, n_thin=1, n_chains=NCH, n_temps=1,
-                    set_starting_model=True, out_filename=None)
+                    set_starting_model=True, write_results=False)
     drawn = []
     orig = inv._draws
 

@@ -252,11 +252,11 @@ def test_inversion_with_layer_counts(oracle):
     counts = np.array([2, 3, 4, 5, 6, 3, 3, 2], dtype=np.int32)
     np.random.seed(4)
     inv = Inversion(data, mp, "normal", noise, n_burn=0, n_chunk=50, n_mcmc=50, n_chains=1,
-                    n_temps=None, layer_counts=None)
+                    n_temps=None, layer_counts=None, write_results=False)
     assert inv.layer_counts is None
     np.random.seed(4)
     inv = Inversion(data, mp, "normal", noise, n_burn=0, n_chunk=25, n_mcmc=50, n_thin=2,
-                    n_chains=8, n_temps=1, layer_counts=counts)
+                    n_chains=8, n_temps=1, layer_counts=counts, write_results=False)
     start = inv.state.m.cpu().numpy().copy()
     inv.random_walk(mp, "cauchy")
     end = inv.state.m.cpu().numpy()

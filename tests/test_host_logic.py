@@ -1,4 +1,6 @@
-"""CPU tests: host logic, ABI surface, and the world_size-2 sharded tempering exchange (gloo)."""
+"""CPU tests: host logic, ABI surface, and the world_size-2 sharded tempering exchange over
+gloo through the sampler's own collective (tests/test_gpu_two_ranks.py runs the whole sharded
+sampler with two ranks on a GPU)."""
 import ctypes
 import os
 import re
@@ -24,6 +26,7 @@ def test_library_exports_every_declared_symbol():
     # struct layouts agree with the header's field order and sizes
     assert ctypes.sizeof(L.Problem) == 8 * 4 + 3 * 8 + 6 * 8 + 2 * 4
     assert ctypes.sizeof(L.Chains) == 12 * 8
+    assert ctypes.sizeof(L.Diag) == 3 * 8
 
 
 def test_argument_validation_without_gpu():
@@ -140,7 +143,7 @@ def _rank_main(rank, world, port, ret, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
-    from mcmc_amd.inversion.inversion import Inversion, gather_chain_values, ladder_layout
+    from mcmc_amd.inversion.inversion import Inversion, all_gather_blocks, ladder_layout
     n_temps, n_ladders = 4, 6
     n = n_temps * n_ladders
     rng = np.random.RandomState(3)           # same stream on every rank
@@ -155,17 +158,24 @@ def _rank_main(rank, world, port, ret, tmp):
         betas = inv.replica_betas(1.3)
         swap_rng = np.random.RandomState(0)
         per = n // world
+        full = torch.zeros(n, dtype=torch.float64)
         for sweep in range(5):
             local = torch.tensor(all_logL[sweep, rank * per:(rank + 1) * per])
-            full = gather_chain_values(local, n, world)
-            betas, _, _ = oracle.tempering_sweep(betas, full, swap_rng.rand(n_ladders, n_temps - 1),
+            # the sampler's own collective (Inversion.gather_logL calls it on device tensors)
+            all_gather_blocks(full, local)
+            betas, _, _ = oracle.tempering_sweep(betas, full.numpy(),
+                                                 swap_rng.rand(n_ladders, n_temps - 1),
                                                  n_temps, n_ladders, rs, ls)
         out[layout] = betas.tolist()
     ret[rank] = out
     # every rank writes the records of its own chains: no two ranks name the same file
     inv = Inversion.__new__(Inversion)
     inv.rank, inv.world, inv.out_dir, inv.out_filename = rank, world, tmp + "/", "run"
-    inv._write_chunk(0, {"model_params": np.full((2, 3), float(rank))})
+    inv._lo, inv.n_local, inv._writer = 2 * rank, 2, None
+    inv._write_chunk(0, {"model_params": [torch.full((2, 3), float(rank))]})
+    # a missing name is made up from rank 0's clock, the same on every rank
+    inv.out_filename = None
+    ret[f"name{rank}"] = inv._clock_name()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -202,4 +212,34 @@ def test_sharded_tempering_two_ranks_gloo(oracle, tmp_path):
         np.testing.assert_array_equal(np.sort(betas[pos], axis=1), np.sort(start[pos], axis=1))
     for r in range(world):
         f = np.load(str(tmp_path) + f"/results-run-r{r}-00000.npz")
-        assert (f["model_params"] == float(r)).all()
+        assert (f["model_params"] == float(r)).all() and f["model_params"].shape == (2, 3)
+        assert f["chain"].tolist() == [2 * r, 2 * r + 1] and int(f["rank"]) == r
+    assert ret["name0"] == ret["name1"] and ret["name0"].isdigit()
+
+
+def test_rates_follow_the_reference_rule():
+    """acc_rate and the error ratios of a record: counts over n_acc + n_rej, 0 while nothing was
+    rejected (src/inversion/model.py:483, :520)."""
+    from mcmc_amd.inversion.inversion import rates_from_counters
+    cnt = np.array([[3, 0, 1, 0, 0], [3, 1, 1, 0, 2], [0, 4, 4, 0, 0]])
+    r = rates_from_counters(cnt)
+    np.testing.assert_array_equal(r["acc_rate"], [0.0, 0.75, 0.0])
+    np.testing.assert_array_equal(r["bounds_err"], [0.0, 0.25, 1.0])
+    np.testing.assert_array_equal(r["fm_err"], [0.0, 0.5, 0.0])
+    np.testing.assert_array_equal(r["physics_err"], [0.0, 0.0, 0.0])
+
+
+def test_stepsize_tuning_of_the_compatibility_model_matches_reference():
+    """Model.stepsize_tuning on the host (one chain) against the reference's trace: the widths
+    after each tuning, given the counters the trace holds at that step."""
+    from mcmc_amd.inversion.model import Model
+    for case in ("3layer_tune", "3layer_tune_individual"):
+        g = load_golden(f"mh_trace_{case}.json")
+        m = Model.__new__(Model)
+        m.proposal_width = np.array(g["width0"])
+        every = g["tune_every"]
+        for s in range(every - 1, len(g["steps"]), every):
+            rec = g["steps"][s]
+            m.acceptance_rate = {"acc_rate": np.asarray(rec["acc_rate"])}
+            m.stepsize_tuning(s)
+            np.testing.assert_array_equal(m.proposal_width, rec["width"])

@@ -125,17 +125,30 @@ def _replay(oracle, g):
         cnt_ind[1, k] += 1 - acc[0]
         cnt_ind[2, k] += status[0] == 1
         cnt_ind[3, k] += status[0] >= 3
+        # Model.stepsize_tuning after every tune_every-th step (the traces that have it)
+        if g.get("tune_every") and (s + 1) % g["tune_every"] == 0:
+            if ind:
+                st.width[:] = oracle.stepsize_tuning(st.width, cnt_ind[0][None], cnt_ind[1][None])
+            else:
+                st.width[:] = oracle.stepsize_tuning(st.width, st.counters[:, 0], st.counters[:, 1])
         yield s, rec, st, acc[0], status[0], (cnt_ind if ind else None)
 
 
 @pytest.mark.parametrize("case", ["3layer_normal", "6layer_normal", "6layer_asymlaplace",
-                                  "3layer_individual_T2", "asymlaplace_WH01"])
+                                  "3layer_individual_T2", "asymlaplace_WH01", "3layer_tune",
+                                  "3layer_tune_individual"])
 def test_mh_trace_bit_exact(oracle, case):
-    """State after every step equals the reference's own Model.perturb_params, bit for bit."""
+    """State after every step equals the reference's own Model.perturb_params, bit for bit; in
+    the two traces with Model.stepsize_tuning (one rate per chain, one per parameter) the
+    proposal widths as well."""
     g = load_golden(f"mh_trace_{case}.json")
     n = 0
+    widths = set()
     for s, rec, st, acc, status, cnt_ind in _replay(oracle, g):
         np.testing.assert_array_equal(st.m[0], rec["m"], err_msg=f"step {s}")
+        if g.get("tune_every"):
+            np.testing.assert_array_equal(st.width[0], rec["width"], err_msg=f"step {s}")
+            widths.update(rec["width"])
         if "asymlaplace" in case:
             assert st.logL[0] == pytest.approx(rec["logL"], rel=1e-13), s
         else:
@@ -153,6 +166,9 @@ def test_mh_trace_bit_exact(oracle, case):
         n += 1
     assert n == len(g["steps"])
     np.testing.assert_array_equal(st.pred[0], g["final_pred"])
+    if g.get("tune_every"):
+        assert max(widths) > 0.05                       # widened ...
+        assert case != "3layer_tune_individual" or min(widths) < 0.05  # ... and narrowed
 
 
 def test_mh_trace_rotation(oracle):

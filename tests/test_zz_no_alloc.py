@@ -80,6 +80,36 @@ def test_static_scratch_entry_point_refuses_what_it_cannot_hold():
     zi = torch.zeros((1, B), dtype=torch.int32, device=prob.device)
     s = ch.struct()
     rc = L.lib().mhd_mh_steps_static(prob.cref(), ctypes.byref(s), B, 1, _ptr(zi), _ptr(z), _ptr(z),
-                                     1.0, 0, 0, None, None, 0, None, None, None, None,
+                                     1.0, 0, 0, None, None, 0, None, None, None, None, None,
                                      _stream(prob.device))
     assert rc == -22 and b"4096" in L.lib().mhd_last_error()
+
+
+def test_static_reset_clears_the_scratch_for_whoever_comes_next():
+    """mhd_static_reset: after it a call adopts its chains without clearing (the rule for
+    callers under graph capture and for allocators that hand out an old address again); the
+    chains are those of mhd_mh_steps whatever the scratch held before."""
+    import torch
+    from mcmc_amd import _lib as L
+    from mcmc_amd.engine import DeviceChains, _stream
+    rng = np.random.default_rng(91)
+    B, S = 128, 60
+    prob, starts = _problem(rng, B)
+    dev, NP = prob.device, 2 * NL + 1
+    idx = torch.tensor(rng.integers(0, NP, (S, B)).astype(np.int32), device=dev)
+    cauchy = torch.tensor(np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5)), device=dev)
+    u_acc = torch.tensor(rng.uniform(size=(S, B)), device=dev)
+    ref = DeviceChains(prob, starts, 0.05)
+    assert int((ref.init_likelihood() != 0).sum()) == 0
+    ref.steps(idx, cauchy, u_acc)
+    for reset in (False, True, True):
+        ch = DeviceChains(prob, starts, 0.05)
+        ch.sched = None
+        assert int((ch.init_likelihood() != 0).sum()) == 0
+        if reset:
+            L.check(L.lib().mhd_static_reset(_stream(dev)))
+        ch.steps(idx[:S // 2], cauchy[:S // 2], u_acc[:S // 2], static_scratch=True)
+        ch.steps(idx[S // 2:], cauchy[S // 2:], u_acc[S // 2:], static_scratch=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ch.m, ref.m) and torch.equal(ch.logL, ref.logL)
+        assert torch.equal(ch.counters, ref.counters)

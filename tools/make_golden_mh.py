@@ -113,7 +113,7 @@ class DrawFeeder:
 
 def run_case(name, n_layers, bounds, periods, true_m, noise_dist, noise_params, n_steps, seed,
              rotate=False, n_burn=0, n_cov_chunk=200, n_thin=1, individual=False, start=None,
-             T=1):
+             T=1, tune_every=0):
     vpvs = 1.75
     rng = np.random.default_rng(seed)
     mp = DispersionCurveParams(n_layers, bounds, {"depth": 0.05, "vel_s": 0.05}, vpvs)
@@ -155,6 +155,11 @@ def run_case(name, n_layers, bounds, periods, true_m, noise_dist, noise_params, 
             for t in range(n_thin):
                 model.perturb_params(data, "cauchy", s, n_burn, 500, t, T=T, rotate_params=rotate)
                 used = feeder.next_step()
+                # acceptance-rate step-size tuning (src/inversion/model.py:538-556; the reference's
+                # own call, after every step, is commented out at :257): here after every
+                # tune_every-th step
+                if tune_every and (s * n_thin + t + 1) % tune_every == 0:
+                    model.stepsize_tuning(s)
                 ar = model.acceptance_rate
                 rec = {
                     "m": mp.model_params.tolist(),
@@ -166,6 +171,8 @@ def run_case(name, n_layers, bounds, periods, true_m, noise_dist, noise_params, 
                     "n_fm_err": np.asarray(ar["n_fm_err"]).tolist(),
                     "acc_rate": np.asarray(ar["acc_rate"]).tolist(),
                 }
+                if tune_every:
+                    rec["width"] = np.asarray(model.proposal_width).tolist()
                 if rotate:
                     rec["n_cov"] = int(model.n_cov)
                     rec["width"] = np.asarray(model.proposal_width).tolist()
@@ -193,6 +200,7 @@ def run_case(name, n_layers, bounds, periods, true_m, noise_dist, noise_params, 
         "rotate": bool(rotate),
         "individual_acceptance": bool(individual),
         "T": T,
+        "tune_every": tune_every,
         "idx": idx.tolist(),
         "u_prop": u_prop.tolist(),
         "u_acc": u_acc.tolist(),
@@ -283,6 +291,11 @@ def main():
     run_case("3layer_rotate", 3, b3, p20, [0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0],
              "normal", {"std": 0.025}, n_steps=60, seed=5, rotate=True, n_burn=10, n_cov_chunk=5,
              n_thin=2)
+    # Model.stepsize_tuning every 25 steps: one rate for the chain, and one per parameter
+    run_case("3layer_tune", 3, b3, p20, [0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0],
+             "normal", {"std": 0.025}, n_steps=300, seed=11, tune_every=25)
+    run_case("3layer_tune_individual", 3, b3, p20, [0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0],
+             "normal", {"std": 0.025}, n_steps=400, seed=12, individual=True, tune_every=40)
     # the reference's one working configuration (src/main.py:380-407 -> :261-347): two layers,
     # asymmetric-Laplace likelihood, the 60 periods and per-period lambda scaling of site WH01
     # (flipped, clipped at 60: src/main.py:313-317), lambd = 1, kappa = 0.75, bounds of
