@@ -33,6 +33,13 @@ def _compile(out, extra, force, verbose):
     return out
 
 
+# The profiling twin (-DMHD_PROFILE): the same kernels with cycle counters per search stage, per
+# chain timings and event counts, read through the mhd_debug_* exports that only this build has
+# (scratch/prof_mh2.py, scratch/prof_short.py).  Not loaded by the package unless MCMC_AMD_LIB
+# names it.
+OUT_PROFILE = os.path.join(HERE, "lib", "libmcmc_amd_prof.so")
+
+
 def build(force=False, verbose=False):
     return _compile(OUT, [], force, verbose)
 
@@ -41,7 +48,13 @@ def build_test_variants(force=False, verbose=False):
     return _compile(OUT_SABOTAGE, ["-DMHD_DEFER_SABOTAGE", "-DMHD_ABORT_SABOTAGE"], force, verbose)
 
 
+def build_profile(force=False, verbose=False):
+    return _compile(OUT_PROFILE, ["-DMHD_PROFILE"], force, verbose)
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     build_test_variants(force="--force" in sys.argv, verbose=True)
+    if "--profile" in sys.argv:
+        build_profile(force="--force" in sys.argv, verbose=True)
     print(OUT)

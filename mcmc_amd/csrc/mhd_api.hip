@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) MHD_REGS void forward_kernel(mhd_problem_t p, c
     for (int k = lane; k < P; k += 64) t[k] = p.periods[k];
     __syncthreads();
     build_layer_table(T, m, layers_of(p, ib), p.vpvs, lane, p.n_layers);
-    EvalCount cnt = {0, 0};
+    EvalCount cnt = {0, 0, 0};
     const int st = (search == 2)
                        ? forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, out,
                                            scratch, cnt, 0, t, t, 0)
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     const long long k_t0 = clock64(), k_w0 = wall_clock64();
     if (lane == 0 && ib < 2048) g_times[2 * ib] = (unsigned long long)k_w0;
 #endif
-    EvalCount cnt = {0, 0};
+    EvalCount cnt = {0, 0, 0};
     // a chain whose curves keep defeating the predictor (densely spaced modes) uses the
     // wave-sequential search for a while, then tries the predictor again
     // (the chain's current phase curve guides the predictor when the chain keeps one)
@@ -541,12 +541,20 @@ __global__ __launch_bounds__(256) void stepsize_tuning_kernel(mhd_chains_t ch, i
 }
 
 // ---- cost-aware launch schedule ---------------------------------------------
-// mhd_chains_t.sched, kept between calls: what a step of each chain cost last time (ticks of
-// the 100 MHz clock, scaled to one candidate in flight; 0 = not known yet), and what the next
-// launch is made from: the chains in order of decreasing cost and the number n4 of chains at
-// the head of that order that run with four candidates in flight.  Somewhat more than 2 * n4
-// chains at its tail run with one candidate, all others with two, so a launch keeps at most two
-// waves per chain on average and the expensive chains finish closer to the others.
+// mhd_chains_t.sched, kept between calls: what a step of each chain costs and what the next
+// launch is made from.  The cost of a chain is counted, not timed: the evaluation rounds its
+// forward models take (EvalCount::rounds of the candidate that is always needed, averaged) times
+// the share of its steps that have a forward model at all (a proposal outside the bounds costs
+// nothing) -- "evaluation rounds per step with one candidate in flight"; 0 = not known yet.  It
+// depends on the chain's path only, so the same run is scheduled the same way every time.  With
+// nw candidates in flight a chain settles consumed(nw, p) forwards per round, p being the share
+// of its forwards it accepted lately.  Only the deadline of a launch needs the clock: the ticks
+// of the 100 MHz counter that one evaluation round took on average in the launch before (one
+// number for all chains, summed in the header).
+// The launch is made from the chains in order of decreasing expected time and the number n4 of
+// chains at the head of that order that run with four candidates in flight.  Somewhat more than
+// 2 * n4 chains at its tail run with one candidate, all others with two, so a launch keeps at
+// most two waves per chain on average and the expensive chains finish closer to the others.
 constexpr int SCHED_MAX_CHAINS = 4096;  // one workgroup sorts them in LDS
 constexpr int SCHED_MIN_CHAINS = 64;    // fewer chains leave the GPU empty however they are ordered
 // a chain gets four candidates when with two it is expected to take longer than this fraction of
@@ -560,14 +568,40 @@ constexpr int SCHED_MIN_CHAINS = 64;    // fewer chains leave the GPU empty howe
 #ifndef SCHED_SPARE_N
 #define SCHED_SPARE_N 64
 #endif
+// share of a chain's steps that have a forward model, before the chain has shown its own
+#ifndef SCHED_PVALID_PRIOR
+#define SCHED_PVALID_PRIOR 0.85f
+#endif
+#ifndef SCHED_PVALID_WEIGHT
+#define SCHED_PVALID_WEIGHT 16.0f
+#endif
+#ifndef SCHED_COST_PRIOR
+#define SCHED_COST_PRIOR 20.0f  // evaluation rounds per step of a chain that has not run a forward yet
+#endif
 constexpr int SCHED_SPARE = SCHED_SPARE_N;           // workgroup places left free in a scheduled launch
-__device__ __constant__ float SCHED_CONSUMED[5] = {0.0f, 1.0f, 1.65f, 2.07f, 2.35f};
+#ifndef SPEC_FIRST_A
+#define SPEC_FIRST_A 0.42f
+#endif
+// Forwards a chain settles per round with nw candidates in flight when it accepts the share p of
+// its forwards: the root of the candidates' tree always, every other node with the probability
+// of the path to it (see mh_steps_multi_kernel for the trees).
+__host__ __device__ inline float sched_consumed(int nw, float p)
+{
+    const float q = 1.0f - p;
+    if (nw <= 1) return 1.0f;
+    if (nw == 2) return 1.0f + (p > 0.5f ? p : q);
+    if (p < SPEC_FIRST_A) return 1.0f + q + q * q + q * q * q;  // R RR RRR
+    if (p < 0.5f) return 1.0f + q + q * q + p;                  // R RR A
+    if (p < 0.68f) return 1.0f + p + q + p * p;                 // A R AA
+    return 1.0f + p + p * p + p * p * p;                        // A AA AAA
+}
 
 struct SchedView {
     float* cost;  // [B]
     int* n4;      // [0] n4, [1] number of split workgroups, [2..3] the deadline of the launch,
                   // [4] n4 of the call's first launch, [5] chains the last launch found unfinished
-                  // (diagnostics), [6..7] unused
+                  // (diagnostics), [6..7] as floats: ticks and evaluation rounds of the launches
+                  // since the last phase 0 (their ratio prices a round for the deadlines)
     int* order;   // [B]
     int* progress;         // [B] steps of the current call each chain has done
     unsigned char* level;  // [B] bits 0-1: SearchPolicy level each chain ended its last launch
@@ -616,6 +650,13 @@ constexpr int SCHED_PHASES_MIN_STEPS = SCHED_MIN_STEPS;
 #define PHASE_DEADLINE_FRACTION 0.8f  // first deadline, in units of the median chain's expected time
 #endif
 
+// the share of its forwards chain i accepted lately (SPEC_PACC_START while not known)
+__device__ __forceinline__ float sched_pacc(const SchedView& v, int i)
+{
+    const int q = (int)v.level[i] >> 2;
+    return q > 0 ? (float)q * (1.0f / 63.0f) : 0.3f;
+}
+
 __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S, int phase,
                                                         int phases, int slots)
 {
@@ -631,13 +672,15 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
         float c = i < B ? v.cost[i] : -1.0f;
         if (i < B && !(c > 0.0f)) unknown = 1;
         if (i < B && phase == 0) v.progress[i] = 0;
-        // later phases: by the work that is left
+        // evaluation rounds per step with two candidates in flight ...
+        if (i < B) c /= sched_consumed(2, sched_pacc(v, i));
+        // ... later phases: of the work that is left
         if (i < B && phase > 0) c *= (float)(S - v.progress[i]);
         key[i] = c;
         val[i] = i < B ? i : -1;
     }
     __syncthreads();
-    // bitonic sort, descending by cost (ties: by chain index, so that the order is definite)
+    // bitonic sort, descending by that (ties: by chain index, so that the order is definite)
     for (int k = 2; k <= n; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -665,21 +708,32 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
     if (threadIdx.x == 0) {
         int n4 = 0, nsplit = 0;
         unsigned long long deadline = 0;
+        // what an evaluation round took lately, in ticks (0: not known, no deadline)
+        float* calib = (float*)(v.n4 + 6);
+        const float tick = calib[1] > 0.0f ? calib[0] / calib[1] : 0.0f;
+        // the same chain's expected rounds per step with four candidates, with one
+        auto with_four = [&](int j) {
+            const float p = sched_pacc(v, val[j]);
+            return key[j] * sched_consumed(2, p) / sched_consumed(4, p);
+        };
+        auto with_one = [&](int j) { return key[j] * sched_consumed(2, sched_pacc(v, val[j])); };
         if (!unknown && phase == 0) {
-            const float with4 = key[0] / SCHED_CONSUMED[4];
+            const float with4 = with_four(0);
             const int cap = sched_cap4(B, 0);
-            while (n4 < cap && key[n4] / SCHED_CONSUMED[2] > SCHED_MARGIN * with4) {
+            while (n4 < cap && key[n4] > SCHED_MARGIN * with4) {
                 const int ns = n4 + 1 + SCHED_SPARE + (n4 + 1) / 2;
                 if (n4 + 1 + 2 * ns >= B) break;
-                const float target = fmaxf(with4, key[n4 + 1] / SCHED_CONSUMED[2]);
-                if (key[B - 2 * ns] > target) break;
+                const float target = fmaxf(with4, key[n4 + 1]);
+                if (with_one(B - 2 * ns) > target) break;
                 ++n4;
                 nsplit = ns;
             }
-            if (PHASE_DEADLINE_FRACTION > 0.0f && phases > 1)
+            if (PHASE_DEADLINE_FRACTION > 0.0f && phases > 1 && tick > 0.0f)
                 deadline = (unsigned long long)wall_clock64() +
-                           (unsigned long long)(PHASE_DEADLINE_FRACTION * key[B / 2] * (float)S /
-                                                SCHED_CONSUMED[2]);
+                           (unsigned long long)(PHASE_DEADLINE_FRACTION * key[B / 2] * (float)S *
+                                                tick);
+            calib[0] = 0.0f;
+            calib[1] = 0.0f;
         } else if (!unknown) {
             // the chains with work left (they come first in the order): four candidates for as
             // many of them as the wave slots allow beside two for the others
@@ -690,10 +744,11 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
             n4 = room < 0 ? 0 : (room < left ? room : left);
             const int cap = sched_cap4(B, phase);
             if (n4 > cap) n4 = cap;
-            if (phase < phases - 1 && left > 0)
+            if (phase < phases - 1 && left > 0 && tick > 0.0f)
                 deadline = (unsigned long long)wall_clock64() +
-                           (unsigned long long)(PHASE_DEADLINE_LATER * key[left / 2] /
-                                                SCHED_CONSUMED[left / 2 < n4 ? 4 : 2]);
+                           (unsigned long long)(PHASE_DEADLINE_LATER * tick *
+                                                (left / 2 < n4 ? with_four(left / 2)
+                                                               : key[left / 2]));
         }
         v.n4[0] = n4;
         v.n4[1] = nsplit;
@@ -856,6 +911,9 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     const ProposalFrame frame = {lo, hi, rg, wid, R, nl, NP, nlmax};
     int c_acc = 0, c_rej = 0, c_bnd = 0, c_fm = 0;
     unsigned long long lit = 0, exec = 0;
+    // evaluation rounds of the forwards of the chain's first candidate (the one that is always
+    // needed and never given up), and how many there were: the chain's cost for the schedule
+    unsigned root_rounds = 0, root_forwards = 0;
     // how the curves of this chain are searched (see SearchPolicy); a chain goes on at the
     // level its last launch ended with
     const bool keeps = ch.sched && B <= SCHED_MAX_CHAINS;
@@ -902,7 +960,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     if (group_kind && p.mode == 0 && search == 2 && writer) {
         wave_sync();
         build_layer_table(T, m, nl, p.vpvs, lane, nlmax);
-        EvalCount extra = {0, 0};
+        EvalCount extra = {0, 0, 0};
         const int st0 = forward_predicted(T, p.wave, p.mode, MHD_GROUP, t, P, p.dc, p.dt, newpred[w],
                                           scratch[w], extra, 0, t, t, 0);
         wave_sync();
@@ -1093,7 +1151,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         }
         int st = MHD_ST_BOUNDS, trouble = 0;
         double lnew = 0.0;
-        EvalCount cnt = {0, 0};
+        EvalCount cnt = {0, 0, 0};
         if (lane == 0) g_PS.abort = (ABORT_SABOTAGE && w > w0 && round_no % 3 == 1) ? 1 : 0;
         ++round_no;
         if (jc < S) {
@@ -1115,6 +1173,10 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             wave_sync();
             if (st == MHD_ST_OK) lnew = loglik_wave(p, newpred[w], scratch[w] + 2 * MAXP, lane);
             exec += cnt.exec;
+            if (mylen == 0) {
+                root_rounds += cnt.rounds;
+                root_forwards += 1;
+            }
             // A candidate that passes its accept test ends the round's steps wherever it is
             // reached, and if it is not reached an earlier one did: either way the candidates
             // after it are not needed, and their waves are told to give their curves up.
@@ -1228,13 +1290,24 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             sched_view(ch.sched, B).level[ib] = (unsigned char)(lv | (q << 2));
         }
         if (scheduled) sched_view(ch.sched, B).progress[ib] = s;
-        if (s > s_begin) {
-            // (a launch that did only part of the call's steps counts by that part)
+        if (s > s_begin && root_forwards > 0) {
+            // evaluation rounds per forward times the share of the steps that had one (with the
+            // prior's weight while the chain has shown few steps); a launch that did only part
+            // of the call's steps counts by that part
             float* cost = sched_view(ch.sched, B).cost;
             const float done = (float)(s - s_begin);
-            const float now = (float)(wall_clock64() - t_begin) * SCHED_CONSUMED[nw] / done;
+            const float pvalid = (done - (float)c_bnd + SCHED_PVALID_PRIOR * SCHED_PVALID_WEIGHT) /
+                                 (done + SCHED_PVALID_WEIGHT);
+            const float now = (float)root_rounds / (float)root_forwards * pvalid;
             const float old = cost[ib];
             cost[ib] = old > 0.0f ? old + SCHED_GAIN * (done / (float)S) * (now - old) : now;
+            // what a round took, for the deadlines of the next call (all chains together)
+            float* calib = (float*)(sched_view(ch.sched, B).n4 + 6);
+            atomicAdd(&calib[0], (float)(wall_clock64() - t_begin));
+            atomicAdd(&calib[1], (float)root_rounds);
+        } else if (s > s_begin && !(sched_view(ch.sched, B).cost[ib] > 0.0f)) {
+            // no forward model yet (every proposal so far left the bounds): an ordinary chain
+            sched_view(ch.sched, B).cost[ib] = SCHED_COST_PRIOR;
         }
     }
     if (writer) {

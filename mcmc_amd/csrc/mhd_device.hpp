@@ -592,6 +592,16 @@ __device__ inline void build_layer_table(LayerTable& T, const double* m, int n_l
 struct EvalCount {
     unsigned long long lit;   // evaluations the sequential algorithm performs
     unsigned long long exec;  // evaluations executed by lanes
+    unsigned rounds;          // evaluation rounds of the wave (one evaluation per lane each; a
+                              // replay pass counts as a round per four periods): what a curve
+                              // costs in time, whatever the lanes' occupancy -- a count that
+                              // does not depend on the clock (the launch schedule's estimates)
+    // one round of `lanes` evaluations (two per lane: two rounds)
+    __device__ __forceinline__ void round(unsigned long long lanes, unsigned n = 1)
+    {
+        exec += lanes;
+        rounds += n;
+    }
 };
 
 __device__ __forceinline__ int mask_bit_sign(unsigned long long neg, unsigned long long pos,
@@ -706,7 +716,7 @@ __device__ __forceinline__ int solve_period_impl(int wave, double t1, double& c1
         SecVal v = {0.0, 0};
         if (act) v = eval_secular(wave, om, x);
         const unsigned long long neg = __ballot(act && v.m < 0.0), pos = __ballot(act && v.m > 0.0);
-        cnt.exec += 57 + np;
+        cnt.round(57 + np);
         if (np) {
             const bool bad = pend && sgni(v.m) != want;
             wave_sync();
@@ -806,7 +816,7 @@ __device__ __forceinline__ int solve_period_impl(int wave, double t1, double& c1
         }
         const SecVal v = eval_secular(wave, omega, pt);
         const unsigned long long neg = __ballot(v.m < 0.0), pos = __ballot(v.m > 0.0);
-        cnt.exec += 64;
+        cnt.round(64);
         for (int j = 0; j < 64; ++j) {
             c2 = scan_next(c1, idir, clow, dc);
             s2 = mask_bit_sign(neg, pos, j);
@@ -843,7 +853,7 @@ __device__ __forceinline__ int solve_period_impl(int wave, double t1, double& c1
         const double pt = 0.5 * (a + b);
         const SecVal v = eval_secular(wave, omega, pt);
         const unsigned long long neg = __ballot(v.m < 0.0), pos = __ballot(v.m > 0.0);
-        cnt.exec += 64;
+        cnt.round(64);
         ++tree_rounds;
         int node = 1;
         while (node < 64) {
@@ -992,7 +1002,7 @@ __device__ MHD_NOINLINE bool flush_deferred(int wave, EvalCount& cnt)
         v = eval_secular(wave, T.pend_omega, T.pend_x[lane]);
     }
     const bool bad = pend && sgni(v.m) != want;
-    cnt.exec += np;
+    cnt.round(np);
     wave_sync();
     if (lane == 0) T.pend_n = 0;
     wave_sync();

@@ -275,7 +275,7 @@ __device__ __forceinline__ int predict_coarse(int wave, const double* t, int kbe
         S.fm[lane] = v.m;
         S.fe[lane] = v.e;
         wave_sync();
-        cnt.exec += (unsigned long long)nlanes;
+        cnt.round((unsigned long long)nlanes);
         if (k0 == 0 && !carry) sigma0 = mask_sign(neg, pos, 0);
 
         int resolved = 0;
@@ -387,7 +387,7 @@ __device__ __forceinline__ int predict_coarse(int wave, const double* t, int kbe
                     S.fm[lane] = vd.m;
                     S.fe[lane] = vd.e;
                     wave_sync();
-                    cnt.exec += (unsigned long long)__popcll(am);
+                    cnt.round((unsigned long long)__popcll(am));
                     const int sd = mask_sign(ng, ps, 0);
                     int j3 = 1;
                     for (; j3 < 64; ++j3) {
@@ -519,7 +519,7 @@ __device__ MHD_NOINLINE int predict_stepwise(int wave, const double* t, int kbeg
     const double cc = T.cc, betmx = T.betmx, cm = T.cc;
     int s1st = s1st_in;
     double cp = cprev;
-    EvalCount mine = {0, 0};
+    EvalCount mine = {0, 0, 0};
     for (int k = kbeg; k < P; ++k) {
         const bool ifirst = (k == 0);
         double c1 = ifirst ? cc : cp - 1.5 * dc;
@@ -535,6 +535,7 @@ __device__ MHD_NOINLINE int predict_stepwise(int wave, const double* t, int kbeg
                 S.shi[k] = (signed char)(int)br[2];
             }
             cnt.exec += mine.exec;
+            cnt.rounds += mine.rounds;
             wave_sync();
             return k + 1;
         }
@@ -549,6 +550,7 @@ __device__ MHD_NOINLINE int predict_stepwise(int wave, const double* t, int kbeg
         cp = c1;
     }
     cnt.exec += mine.exec;
+    cnt.rounds += mine.rounds;
     wave_sync();
     return P;
 }
@@ -589,7 +591,7 @@ __device__ __forceinline__ void predict_refine(int wave, const double* t, int kb
                 fb = (double)S.shi[k];
                 ea = eb = 0;
             }
-            cnt.exec += 2ull * (unsigned long long)__popcll(__ballot(real));
+            cnt.round(2ull * (unsigned long long)__popcll(__ballot(real)), 2);
         }
         const int sa = sgni(fa);
         int sb = sgni(fb);
@@ -633,7 +635,7 @@ __device__ __forceinline__ void predict_refine(int wave, const double* t, int kb
             }
             const unsigned long long todo = __ballot(!done);
             if (todo == 0ull || abort_requested()) break;
-            cnt.exec += (unsigned long long)__popcll(todo);
+            cnt.round((unsigned long long)__popcll(todo));
             if (!done) {
                 const SecVal v = eval_secular(wave, omega, x);
                 x0 = x1;
@@ -762,7 +764,7 @@ __device__ __forceinline__ int predict_hint(int wave, const double* t, int P, do
 #endif
                 break;
             }
-            cnt.exec += (unsigned long long)__popcll(todo);
+            cnt.round((unsigned long long)__popcll(todo));
             SecVal v = {0.0, 0};
             if (!done) v = eval_secular(wave, omega, x);
             const int sv = sgni(v.m);
@@ -1039,6 +1041,7 @@ __device__ MHD_NOINLINE int verify_pass(int wave, const double* t, double tscale
     const int lane = threadIdx.x & 63;
     auto period_of = [&](int i) -> int { return period_of_abscissa(i, kstart, kend); };
     unsigned long long exec = 0;
+    unsigned rounds = 0;
     int first_bad = npts;
 #if !VERIFY_PAIRS
             for (int base = vbeg; base < npts; base += 64) {
@@ -1062,6 +1065,7 @@ __device__ MHD_NOINLINE int verify_pass(int wave, const double* t, double tscale
                 }
                 const unsigned long long mask = __ballot(bad);
                 exec += (unsigned long long)__popcll(__ballot(act));
+                rounds += 1;
                 if (mask) {
                     first_bad = base + (int)__ffsll((long long)mask) - 1;
                     break;
@@ -1100,6 +1104,7 @@ __device__ MHD_NOINLINE int verify_pass(int wave, const double* t, double tscale
                 }
                 const unsigned long long m0 = __ballot(bad0), m1 = __ballot(bad1);
                 exec += (unsigned long long)(__popcll(__ballot(act0)) + __popcll(__ballot(act1)));
+                rounds += 2;
                 if (m0 | m1) {
                     const int f0 = m0 ? base + 2 * ((int)__ffsll((long long)m0) - 1) : npts;
                     const int f1 = m1 ? base + 2 * ((int)__ffsll((long long)m1) - 1) + 1 : npts;
@@ -1109,6 +1114,7 @@ __device__ MHD_NOINLINE int verify_pass(int wave, const double* t, double tscale
             }
 #endif
     cnt.exec += exec;
+    cnt.rounds += rounds;
     return first_bad;
 }
 
@@ -1167,6 +1173,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
         // any, is not a plain case and ends the pass
         const ReplayPass rp = replay_pass(kstart, nP, c, cc, dc, betmx + dc, betmx, s1st);
         const int npts = rp.npts, kfail = rp.kfail, kplain = rp.kplain, kend = rp.kend;
+        cnt.rounds += (unsigned)(kend - kstart + 3) >> 2;
 #ifdef MHD_PROFILE
         if (kplain >= 0) CHAIN_EVENT(7)
 #endif

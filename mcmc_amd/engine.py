@@ -4,6 +4,7 @@ torch is used for device memory and streams only; all arithmetic of the hot
 path runs in the HIP kernels of mcmc_amd/csrc through include/mcmc_amd.h.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -195,6 +196,8 @@ class DeviceChains:
                 and self.beta.is_contiguous() and self.beta.device == self.m.device
         self.n_evals = torch.zeros(2, dtype=torch.int64, device=dev)
         self.sched = torch.zeros(int(L.lib().mhd_sched_bytes(B)), dtype=torch.uint8, device=dev)
+        if os.environ.get("MCMC_AMD_NO_SCHED"):  # (A/B measurements: calls without the schedule)
+            self.sched = None
 
     def struct(self):
         return L.Chains(

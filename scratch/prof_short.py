@@ -33,7 +33,7 @@ lib.mhd_debug_chain(cc)
 ev=np.array(list(cc),dtype=np.int64).reshape(1024,32)
 order=np.argsort(dur)
 names={0:"fwd",1:"hint",2:"hintfail",4:"repair",5:"repredict",6:"sameroot",7:"notplain",8:"samec",9:"stepwise",10:"seqfinish",26:"resync"}
-for label,idxs in (("median 3",order[510:513]),("slowest 8",order[-8:])):
+for label,idxs in (("median 3",order[510:513]),("slowest 40",order[-40:])):
     print(label)
     for i in idxs:
         print("  chain %4d dur %5.0f us rounds %2d fw %2d | Mcyc predict %.2f refine %.2f replay %.2f verify %.2f repair %.2f giveup %.2f | "%(i,dur[i],rounds[i],fw[i],*(b[i,j]/1e6 for j in range(6)))+" ".join("%s %d"%(n,ev[i,k]) for k,n in names.items()))
