@@ -1,12 +1,13 @@
 // mhd_math.hpp -- small FP64 elementary functions for the secular-function
 // kernels.  Written for straight-line VALU code on gfx950: no tables, no
 // divisions, no slow paths inside the argument ranges the kernels use.  The
-// same source compiles for the host (tests/test_math_host.py builds it with g++)
-// so accuracy is checked against libm without a GPU.
+// same source compiles for the host (tests/test_host_logic.py builds tests/host/math_check.cpp
+// with g++) so accuracy is checked against long-double libm without a GPU.
 //
 //   sincos_pio2(x, s, c)  |x| <= 1e5: three-constant Cody-Waite reduction by
 //                         pi/2 (exact products through fma) + the classic
-//                         degree-13 / degree-14 minimax kernels; < 1 ulp.
+//                         degree-13 / degree-14 minimax kernels; 1.5 ulp at most
+//                         (measured over |x| in [1e-2, 1e5], tests/host/math_check.cpp).
 //   exp_neg(y)            exp(-y) for 0 <= y <= 700: ln2 hi/lo reduction +
 //                         degree-13 polynomial + ldexp; < 1 ulp.
 //   rsqrt_pos(x)          1/sqrt(x), x > 0 normal: hardware seed (device) or

@@ -1027,13 +1027,22 @@ __device__ __forceinline__ int period_of_abscissa(int i, int kstart, int kend)
     return a;
 }
 
+#ifndef VERIFY_OUT_OF_LINE
+#define VERIFY_OUT_OF_LINE 1
+#endif
+#if VERIFY_OUT_OF_LINE
+#define VERIFY_INLINE MHD_NOINLINE
+#else
+#define VERIFY_INLINE __forceinline__
+#endif
+
 // ---- stage 4 ----------------------------------------------------------------
 // Really evaluates abscissae vbeg..npts-1 of the replay pass over periods kstart..kend-1 and
 // returns the first whose sign is not the inferred one (or whose value is not the answer the
 // replay gave for its period), npts if there is none, -1 if the curve was given up (see
 // abort_requested).  Out of line, with the pair evaluation
 // inlined: its registers are saved once per pass, not once per round.
-__device__ MHD_NOINLINE int verify_pass(int wave, const double* t, double tscale, double dc,
+__device__ VERIFY_INLINE int verify_pass(int wave, const double* t, double tscale, double dc,
                                         const double* c, int kstart, int kend, int kfail,
                                         int vbeg, int npts, EvalCount& cnt)
 {
