@@ -179,7 +179,11 @@ __device__ __forceinline__ double rayleigh_compound(const LayerTable& T, double 
         double cosp, w, x, ep, pex, cosq, y, z, eq, sex;
         osc_or_evan(k, xka, dpth, cosp, w, x, ep, pex);
         osc_or_evan(k, xkb, dpth, cosq, y, z, eq, sex);
-        const double a0 = (pex + sex < 60.0) ? ep * eq : 0.0;
+        // exp(-(pex + sex)); the reference sets it to 0 from an exponent of 60 on, where it is
+        // below 1e-26 of the cosine product it is subtracted from: the same number in double
+        (void)pex;
+        (void)sex;
+        const double a0 = ep * eq;
         const double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w,
                      cqx = cosq * x, xy = x * y, xz = x * z, wy = w * y, wz = w * z;
         gamm1 = gam - 1.0;
@@ -412,7 +416,7 @@ __device__ __forceinline__ void secular_rayleigh2(const LayerTable& T, const dou
         for (int u = 0; u < 2; ++u) {
             const double gammk = tb2 * inv_om2[u];
             const double gam = gammk * k2[u];
-            const double a0 = (pex[u] + sex[u] < 60.0) ? ep[u] * eq[u] : 0.0;
+            const double a0 = ep[u] * eq[u];  // (see rayleigh_compound)
             const double cpcq = cosp[u] * cosq[u], cpy = cosp[u] * y[u], cpz = cosp[u] * z[u],
                          cqw = cosq[u] * w[u], cqx = cosq[u] * x[u], xy = x[u] * y[u],
                          xz = x[u] * z[u], wy = w[u] * y[u], wz = w[u] * z[u];

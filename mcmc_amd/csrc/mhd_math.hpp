@@ -10,8 +10,9 @@
 //                         (measured over |x| in [1e-2, 1e5], tests/host/math_check.cpp).
 //   exp_neg(y)            exp(-y) for 0 <= y <= 700: ln2 hi/lo reduction +
 //                         degree-13 polynomial + ldexp; < 1 ulp.
-//   rsqrt_pos(x)          1/sqrt(x), x > 0 normal: hardware seed (device) or
-//                         1/sqrt (host) refined by two Newton steps.
+//   rsqrt_pos(x)          1/sqrt(x), x > 0 normal: hardware seed (device) or a
+//                         single-precision one (host) refined by one step of third
+//                         order; < 1 ulp.
 #pragma once
 #include <cmath>
 
@@ -120,23 +121,15 @@ MHD_HD double exp_neg(double y)
 MHD_HD double rsqrt_pos(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    double y = __builtin_amdgcn_rsq(x);
+    const double y = __builtin_amdgcn_rsq(x);
 #else
-    double y = (double)(1.0f / __builtin_sqrtf((float)x));  // a seed of similar quality
+    const double y = (double)(1.0f / __builtin_sqrtf((float)x));  // a seed of similar quality
 #endif
-    // y <- y + y*(1/2 - x*y*y/2) twice (quadratic convergence)
-    double h = 0.5 * y;
-    double e = fma_(-x * y, h, 0.5);
-    y = fma_(y, e, y);
-    h = 0.5 * y;
-    e = fma_(-x * y, h, 0.5);
-    y = fma_(y, e, y);
-#if !defined(__HIP_DEVICE_COMPILE__)
-    h = 0.5 * y;  // the float seed is only 24 bits: one more step on the host
-    e = fma_(-x * y, h, 0.5);
-    y = fma_(y, e, y);
-#endif
-    return y;
+    // one step of third order: with e = 1 - x y^2 (|e| < 2^-22 for either seed)
+    // 1/sqrt(x) = y (1 - e)^(-1/2) = y (1 + e/2 + 3 e^2/8 + O(e^3))
+    const double e = fma_(-(x * y), y, 1.0);
+    const double q = e * fma_(e, 0.375, 0.5);
+    return fma_(y, q, y);
 }
 
 }  // namespace mhd
