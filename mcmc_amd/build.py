@@ -49,7 +49,7 @@ def build_test_variants(force=False, verbose=False):
 
 
 def build_profile(force=False, verbose=False):
-    return _compile(OUT_PROFILE, ["-DMHD_PROFILE"], force, verbose)
+    return _compile(OUT_PROFILE, ["-DMHD_PROFILE", "-Wno-unused-value"], force, verbose)
 
 
 if __name__ == "__main__":

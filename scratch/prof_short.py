@@ -31,12 +31,13 @@ print("duration us: mean %.0f p50 %.0f p90 %.0f max %.0f; corr(rounds,duration) 
 cc=(ctypes.c_uint*32768)()
 lib.mhd_debug_chain(cc)
 ev=np.array(list(cc),dtype=np.int64).reshape(1024,32)
-order=np.argsort(dur)
+order=np.argsort(en) if int(steps) >= 100 else np.argsort(dur)
+last_start=b[:,5]
 names={0:"fwd",1:"hint",2:"hintfail",4:"repair",5:"repredict",6:"sameroot",7:"notplain",8:"samec",9:"stepwise",10:"seqfinish",26:"resync"}
 for label,idxs in (("median 3",order[510:513]),("slowest 40",order[-40:])):
     print(label)
     for i in idxs:
-        print("  chain %4d dur %5.0f us rounds %2d fw %2d | Mcyc predict %.2f refine %.2f replay %.2f verify %.2f repair %.2f giveup %.2f | "%(i,dur[i],rounds[i],fw[i],*(b[i,j]/1e6 for j in range(6)))+" ".join("%s %d"%(n,ev[i,k]) for k,n in names.items()))
+        print("  chain %4d end %6.0f us (last launch from step %3d with %d waves) dur %5.0f us rounds %2d fw %2d | Mcyc predict %.2f refine %.2f replay %.2f verify %.2f repair %.2f giveup %.2f | "%(i,en[i],int(last_start[i])>>32,int(last_start[i])&0xffffffff,dur[i],rounds[i],fw[i],*(b[i,j]/1e6 for j in range(6)))+" ".join("%s %d"%(n,ev[i,k]) for k,n in names.items()))
 tot=ev.sum(axis=0)
 print("all chains: forwards %d hint tried %d gave up %d | repairs %d (after a settled hint %d) | sequential answer above/below/at the predicted root %d/%d/%d | first wrong sign in scan %d in halvings %d | resynced %d repredicted %d seqfinish %d notplain %d"%(tot[0],tot[1],tot[2],tot[4],tot[27],tot[16],tot[17],tot[18],tot[19],tot[20],tot[26],tot[5],tot[10],tot[7]))
 rep=ev[:,4]/np.maximum(ev[:,0],1)
