@@ -132,6 +132,9 @@ def main():
                          "(RCCL) and run the exchange sweep, inside the timed region")
     ap.add_argument("--temps", type=int, default=64)
     ap.add_argument("--thin", type=int, default=10, help="MH steps between two exchange sweeps")
+    ap.add_argument("--ladder", choices=["reference", "geometric"], default="reference",
+                    help="reference: 1/1.15**ind from the first tempered rung on (the reference's "
+                         "formula); geometric: 1/1.15, 1/1.15**2, ... right after the cold quarter")
     args = ap.parse_args()
     headline = (args.layers, args.itype, args.wave, args.rotation, args.chains, args.tempering) == \
         (N_LAYERS, "phase", "rayleigh", "off", CHAINS_PER_GPU, False)
@@ -192,7 +195,7 @@ def main():
         n_ladders = world * B // args.temps
         nf = int(np.ceil(args.temps / 4))
         ladder = np.ones(args.temps)
-        ladder[nf:] = 1.0 / 1.15 ** np.arange(nf, args.temps)
+        ladder[nf:] = 1.0 / 1.15 ** (np.arange(nf, args.temps) - (nf - 1 if args.ladder == "geometric" else 0))
         beta_all = torch.tensor(np.tile(ladder, n_ladders), device=prob.device)
         logL_all = torch.zeros(world * B, dtype=torch.float64, device=prob.device)
         swap_counts = torch.zeros(2, dtype=torch.int64, device=prob.device)
@@ -291,6 +294,7 @@ def main():
                 "search": args.search,
                 "candidates_in_flight": args.candidates, "acceptance_rate": round(acc_rate, 4),
                 **({"temperatures": args.temps, "steps_between_sweeps": args.thin,
+                    "beta_ladder": args.ladder,
                     "exchanges_accepted_proposed": swap_counts.tolist()}
                    if args.tempering else {}),
             },

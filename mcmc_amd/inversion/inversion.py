@@ -20,6 +20,10 @@ Differences from the reference, all deliberate:
     changes nothing (and raises AttributeError on its uninitialised counters,
     src/inversion/inversion.py:586-596).  Here an accepted exchange swaps the
     two betas, and a chain's accept test uses exp(beta*dlogL/T).
+  * beta_ladder="geometric" (not in the reference; the default "reference" keeps its
+    formula): the tempered rungs are 1/f, 1/f^2, ... right after the cold quarter, instead of
+    1/f^ind from ind = ceil(n/4) on -- with 64 rungs and f = 1.15 the reference's first
+    tempered rung sits at beta = 0.107, and hardly any exchange reaches the cold chains.
   * n_temps (not in the reference): n_chains independent temperature ladders of
     n_temps rungs each, n_temps * n_chains replicas in all, exchanges inside each
     ladder.  Without it the reference's meaning holds: n_chains > 1 is ONE ladder
@@ -196,7 +200,8 @@ class Inversion:
                  beta_spacing_factor=None, out_filename=None, set_starting_model=False,
                  out_dir="./results/inversion/", reference_betas=False, swap_seed=0,
                  n_temps=None, layout="ladder", layer_counts=None, tune_stepsize=None,
-                 write_results=True, record_diagnostics="step", async_sink=True):
+                 write_results=True, record_diagnostics="step", async_sink=True,
+                 beta_ladder="reference"):
         import torch.distributed as dist
         self.data = data
         self.n_burn, self.n_chunk, self.n_mcmc, self.n_thin = n_burn, n_chunk, n_mcmc, n_thin
@@ -206,6 +211,9 @@ class Inversion:
         self.noise_dist, self.noise_params = noise_dist, noise_params
         self.n_chains = n_chains
         self.reference_betas = reference_betas
+        if beta_ladder not in ("reference", "geometric"):
+            raise ValueError("beta_ladder must be 'reference' or 'geometric'")
+        self.beta_ladder = beta_ladder
         if tune_stepsize is not None and int(tune_stepsize) < 1:
             raise ValueError("tune_stepsize: a number of outer steps, or None")
         self.tune_stepsize = None if tune_stepsize is None else int(tune_stepsize)
@@ -265,7 +273,13 @@ class Inversion:
         n_frac = int(np.ceil(n_temps / 4))
         betas = np.zeros(n_temps, dtype=float) if self.reference_betas else np.ones(n_temps)
         inds = np.arange(n_frac, n_temps)
-        betas[inds] = 1.0 / beta_spacing_factor ** inds
+        if getattr(self, "beta_ladder", "reference") == "geometric":
+            # (not in the reference) the tempered rungs continue geometrically from the cold
+            # ones: 1/f, 1/f^2, ... instead of starting at 1/f^n_frac, a jump from 1 that few
+            # exchanges cross when the ladder is long
+            betas[inds] = 1.0 / beta_spacing_factor ** (inds - n_frac + 1)
+        else:
+            betas[inds] = 1.0 / beta_spacing_factor ** inds
         return betas
 
     def replica_betas(self, beta_spacing_factor):

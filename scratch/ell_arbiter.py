@@ -1,5 +1,6 @@
-"""cfg 28 of scratch/soak_mh.py on the CPU only: the oracle's chain 58 at the end, and the
-ellipticity at its second period in extended precision (the kernels gave 0.343807246923192)."""
+"""One configuration of scratch/soak_mh.py on the CPU only: the oracle's chain at the end, and the
+ellipticity at one period in extended precision.  usage: ell_arbiter.py [cfg chain period kernels_value]
+(cfg 28 chain 58 period 1: the kernels gave 0.343807246923192; cfg 34 chain 56 period 1: 0.60217120138619)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -8,7 +9,10 @@ sys.path.insert(0, os.path.join(ROOT, "scratch"))
 import secular_ld as SL
 LD = np.longdouble
 
-r = 28
+r = int(sys.argv[1]) if len(sys.argv) > 1 else 28
+CH = int(sys.argv[2]) if len(sys.argv) > 2 else 58
+KP = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+KV = float(sys.argv[4]) if len(sys.argv) > 4 else 0.343807246923192
 rng = np.random.default_rng(7000 + r)
 nl = int(rng.integers(2, 9)); NP = 2 * nl + 1
 P = int(rng.choice([10, 20, 40]))
@@ -29,7 +33,7 @@ obs = tc + noise["std"] * rng.standard_normal(ND)
 starts = np.tile(true_m, (B, 1)) * rng.uniform(0.9, 1.1, (B, NP))
 starts = np.clip(np.stack([oracle.sort_layers(s, nl) for s in starts]), bounds[:, 0], bounds[:, 1])
 beta = rng.uniform(0.2, 1.0, B) if rng.uniform() < 0.4 else None
-assert beta is None and rotate == 0
+assert rotate == 0
 ost, ovel, _ = oracle.forward_batch(starts, nl, 1.75, periods, itype=3, nthreads=8)
 ologL = np.array([oracle.loglik(obs, v, "normal", noise) for v in ovel])
 st = oracle.ChainState(starts, ologL, ovel, 0.05, bounds)
@@ -39,12 +43,13 @@ for c in range(ncall):
     cz = np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5))
     ua = rng.uniform(size=(S, B))
     for s in range(S):
-        oracle.mh_step(st, idx[s], cz[s], ua[s], nl, 1.75, periods, obs, "normal", noise, itype=3)
-m = st.m[58]
+        oracle.mh_step(st, idx[s], cz[s], ua[s], nl, 1.75, periods, obs, "normal", noise, beta=beta, itype=3)
+m = st.m[CH]
 print("model", repr(m.tolist()))
-print("oracle pred phase[1] %.15g ell[1] %.15g" % (st.pred[58, 1], st.pred[58, P + 1]))
+print("kernels' value %.15g" % KV)
+print("oracle pred phase[k] %.15g ell[k] %.15g" % (st.pred[CH, KP], st.pred[CH, P + KP]))
 lt = oracle.layer_table(m, nl, 1.75)
-c = st.pred[58, 1]; T = periods[1]
+c = st.pred[CH, KP]; T = periods[KP]
 e = oracle.compound(*lt, T, c)
 print("compound vector (double):", e)
 # extended precision: the same recursion, all five components

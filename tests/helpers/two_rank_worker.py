@@ -1,4 +1,4 @@
-"""One rank of the two-rank tempering test (tests/test_gpu_two_ranks.py), started as a process
+"""One rank of the two-rank tempering test (tests/test_zy_two_ranks.py), started as a process
 of its own before anything touches the GPU:
 
     python two_rank_worker.py RANK WORLD PORT OUT_DIR LAYOUT

@@ -186,3 +186,34 @@ def test_the_binding_shown_to_maintainers_works(oracle):
     ost, ovel, _ = oracle.forward_batch(params, nl, 1.75, periods)
     assert (st == ost).all() and (ost == 0).any()
     assert np.array_equal(vel[ost == 0], ovel[ost == 0])
+
+
+def test_device_spellings_and_geometric_ladder(oracle):
+    """DeviceProblem takes "cuda", torch.device("cuda") and "cuda:0" alike (the index is made
+    explicit before mhd_init sees it); a tempered run on the non-default geometric ladder keeps
+    its betas a permutation of that ladder and exchanges with the cold chains."""
+    import torch
+    from mcmc_amd.engine import DeviceProblem
+    from mcmc_amd.inversion import Data, Inversion
+    periods = np.flip(1 / np.logspace(0.3, 1.3, 20)).copy()
+    for dev in ("cuda", torch.device("cuda"), "cuda:0", None):
+        prob = DeviceProblem(3, 1.75, periods, device=dev)
+        assert prob.device == torch.device("cuda", torch.cuda.current_device())
+    with pytest.raises(Exception):
+        DeviceProblem(3, 1.75, periods, device="cpu")
+    mp = _mp(3)
+    true_m = np.array([0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0])
+    obs = oracle.forward(true_m, 3, 1.75, periods)[1]
+    noise = {"std": 0.025}
+    data = Data(periods, obs, "normal", noise)
+    data.model_true = true_m
+    np.random.seed(2)
+    inv = Inversion(data, mp, "normal", noise, n_burn=0, n_chunk=20, n_mcmc=20, n_thin=2,
+                    n_chains=4, n_temps=16, beta_spacing_factor=1.15, set_starting_model=True,
+                    beta_ladder="geometric", write_results=False)
+    ladder = inv.get_betas(1.15, 16)
+    np.testing.assert_allclose(ladder[:6], [1, 1, 1, 1, 1 / 1.15, 1 / 1.15 ** 2], rtol=1e-15)
+    inv.random_walk(mp, "cauchy")
+    got = inv.betas.reshape(4, 16)
+    np.testing.assert_array_equal(np.sort(got, axis=1)[:, ::-1], np.tile(ladder, (4, 1)))
+    assert inv.swap_acc > 0

@@ -1,5 +1,5 @@
 """CPU tests: host logic, ABI surface, and the world_size-2 sharded tempering exchange over
-gloo through the sampler's own collective (tests/test_gpu_two_ranks.py runs the whole sharded
+gloo through the sampler's own collective (tests/test_zy_two_ranks.py runs the whole sharded
 sampler with two ranks on a GPU)."""
 import ctypes
 import os
@@ -97,6 +97,33 @@ def test_get_betas_reference_and_fixed():
         want = np.array(want)
         np.testing.assert_array_equal(fixed[want > 0], want[want > 0])
         assert (fixed[want == 0] == 1).all()
+
+
+def test_geometric_ladder_option():
+    """beta_ladder="geometric": the cold quarter at 1, then 1/f, 1/f^2, ... without the
+    reference's jump; the default stays the reference's formula."""
+    from mcmc_amd.inversion.inversion import Inversion
+    inv = Inversion.__new__(Inversion)
+    inv.n_chains, inv.reference_betas, inv.beta_ladder = 8, False, "geometric"
+    b = inv.get_betas(1.15)
+    np.testing.assert_allclose(b, [1, 1] + [1.15 ** -k for k in range(1, 7)], rtol=1e-15)
+    inv.beta_ladder = "reference"
+    np.testing.assert_allclose(inv.get_betas(1.15), [1, 1] + [1.15 ** -k for k in range(2, 8)],
+                               rtol=1e-15)
+
+
+def test_stepsize_tuning_argument_validation_without_gpu():
+    from mcmc_amd import _lib as L
+    lib = L.lib()
+    p = L.Problem(n_layers=3, n_periods=8, dc=0.005, dt=0.025, vpvs=1.75, periods=1)
+    assert lib.mhd_stepsize_tuning(ctypes.byref(p), None, 4, None) == -22
+    ch = L.Chains()
+    assert lib.mhd_stepsize_tuning(ctypes.byref(p), ctypes.byref(ch), 4, None) == -22
+    ch = L.Chains(width=8, counters=8)
+    assert lib.mhd_stepsize_tuning(ctypes.byref(p), ctypes.byref(ch), 0, None) == 0
+    assert lib.mhd_stepsize_tuning(ctypes.byref(p), ctypes.byref(ch), -1, None) == -22
+    assert lib.mhd_sched_min_steps() == 24
+    assert lib.mhd_static_reset(None) == -22     # mhd_init() has not been called: no device
 
 
 def test_tempering_sweep_rule(oracle):

@@ -72,39 +72,47 @@ def test_ill_conditioned_root_is_not(oracle):
     assert 3e-9 < shift < 3e-8, shift
 
 
-# chain state found by a soak of Metropolis-Hastings runs on the joint phase + ellipticity
-# datum: the one ellipticity value (second period) where kernels and oracle differ by 1.1e-7
-ELL = dict(
-    m=[0.05160341851117689, 0.05951657854607631, 0.07420830822504608, 0.07705787426862445,
-       0.07716514539431667, 0.09009329451792748, 0.09151673460925921, 0.14707669378700763,
-       1.2056468271229324, 0.3863159883485392, 0.2965223431728405, 1.112848551167075,
-       0.3949744621748448, 1.2262176172964894, 0.9263579844173467, 1.5110346241551678,
-       1.3244496498132348],
-    nl=8, vpvs=1.75, k=1, kernels=0.343807246923192)
+# chain states found by soaks of Metropolis-Hastings runs on the joint phase + ellipticity
+# datum: the ellipticity values (second period both times) where kernels and oracle differ by
+# more than 1e-8 relative (1.1e-7 and 1.4e-8)
+ELL = [
+    dict(m=[0.05160341851117689, 0.05951657854607631, 0.07420830822504608, 0.07705787426862445,
+            0.07716514539431667, 0.09009329451792748, 0.09151673460925921, 0.14707669378700763,
+            1.2056468271229324, 0.3863159883485392, 0.2965223431728405, 1.112848551167075,
+            0.3949744621748448, 1.2262176172964894, 0.9263579844173467, 1.5110346241551678,
+            1.3244496498132348],
+         nl=8, vpvs=1.75, k=1, kernels=0.343807246929775, own_error=1e-8, small=2e-4, spike=5e-3),
+    dict(m=[0.08342111660377184, 0.08342774206515918, 0.1169909315779275, 0.12249249122520785,
+            1.179097633261282, 1.7250264018417878, 0.5998844222091672, 1.9583888773005202,
+            1.6438060470643951],
+         nl=4, vpvs=1.75, k=1, kernels=0.60217120138619, own_error=5e-9, small=2e-4, spike=1e-3),
+]
 
 
-def test_ellipticity_of_a_mode_that_hardly_moves_the_surface(oracle):
-    """At that period the root of the period equation is a spike (e0 jumps between -9.8e-3 and
-    +9.8e-3 of the largest component within 3e-7 relative), the search's answer lies beside it,
-    and the ratio evaluated there rests on a component that is 1e-4 of the others: the oracle's
-    double-precision value is itself 3e-8 away from the extended-precision one, so no
-    double-precision implementation pins this value to 1e-8.  (The kernels' value is as close to
-    the extended-precision one as the oracle's, within a factor of three.)"""
+@pytest.mark.parametrize("case", ELL, ids=["8 layers", "4 layers"])
+def test_ellipticity_of_a_mode_that_hardly_moves_the_surface(oracle, case):
+    """At that period the root of the period equation is a spike (e0 jumps between about -1e-3
+    and +1e-3 of the largest component, or ten times that, within 3e-7 relative), the search's
+    answer lies beside it, and the ratio evaluated there rests on a component that is 1e-4 of the
+    others: the oracle's double-precision value is itself 9e-9 to 3e-8 away from the
+    extended-precision one, so no double-precision implementation pins this value to 1e-8.  (The
+    kernels' value is as close to the extended-precision one as the oracle's, within a factor of
+    three; in the second case it is the closer of the two.)"""
     import secular_ld as SL
     P = 20
     periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
-    st, vel, _ = oracle.forward(ELL["m"], ELL["nl"], ELL["vpvs"], periods, itype=3)
+    st, vel, _ = oracle.forward(case["m"], case["nl"], case["vpvs"], periods, itype=3)
     assert st == 0
-    k = ELL["k"]
+    k = case["k"]
     c, ell_d = vel[k], vel[P + k]
-    lt = oracle.layer_table(ELL["m"], ELL["nl"], ELL["vpvs"])
+    lt = oracle.layer_table(case["m"], case["nl"], case["vpvs"])
     ev = SL.compound_ld(*lt, periods[k], c)
     wav = np.longdouble(2) * np.arctan2(np.longdouble(0), np.longdouble(-1)) / periods[k] / c
     ell_l = float(-wav * ev[2] / ev[1])
     assert abs(ev[1]) >= abs(ev[3])          # the branch the oracle takes: -k e2 / e1
     assert ell_d == pytest.approx(ell_l, rel=2e-7)
-    assert abs(ell_d / ell_l - 1) > 1e-8     # double precision misses the 1e-8 gate by itself
-    assert abs(ELL["kernels"] / ell_l - 1) < 3 * abs(ell_d / ell_l - 1)
-    assert abs(float(ev[2])) < 2e-4 * float(np.abs(ev).max())
+    assert abs(ell_d / ell_l - 1) > case["own_error"]     # double precision's own error
+    assert abs(case["kernels"] / ell_l - 1) < 3 * abs(ell_d / ell_l - 1)
+    assert abs(float(ev[2])) < case["small"] * float(np.abs(ev).max())
     lo, hi = (float(SL.compound_ld(*lt, periods[k], c * (1 + s))[0]) for s in (-3e-7, 3e-7))
-    assert lo < -5e-3 and hi > 5e-3
+    assert lo < -case["spike"] and hi > case["spike"]
