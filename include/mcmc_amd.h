@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MHD_ABI_VERSION 5
+#define MHD_ABI_VERSION 6
 
 #define MHD_OK 0
 #define MHD_EINVAL (-22) /* bad argument (size beyond a compiled limit, NULL pointer) */
@@ -76,6 +76,12 @@ extern "C" {
 /* rotate flags of mhd_mh_steps */
 #define MHD_ROT_ACCUMULATE 1 /* update_covariance_matrix before proposing  */
 #define MHD_ROT_FRAME 2      /* propose in the rotated (principal-component) frame */
+/* in the same mask: the reference's "uniform" proposal (src/inversion/model.py:205-207)
+   instead of the Cauchy one.  cauchy[s,b] then holds the uniform draw u itself and the
+   perturbed parameter -- normalised by its bounds, in the rotated frame with MHD_ROT_FRAME --
+   is SET to bounds_lo[idx] + u: the reference's arithmetic, which adds the physical lower
+   bound to a normalised value.  proposal_width is not used. */
+#define MHD_PROPOSE_UNIFORM 4
 
 /*
  * Static description of one inversion problem: the parameterisation of
@@ -251,10 +257,11 @@ int mhd_loglik_batch(const mhd_problem_t *prob, const double *pred /* device [B,
  *
  * Draws are host-supplied, one triple per (step, chain):
  *   idx[s,b]    the perturbed parameter      (np.random.randint, model.py:196)
- *   cauchy[s,b] tan(pi*(u-1/2))              (model.py:210-212)
+ *   cauchy[s,b] tan(pi*(u-1/2))              (model.py:210-212; with
+ *               MHD_PROPOSE_UNIFORM the draw u of model.py:207)
  *   u_acc[s,b]  the accept uniform           (model.py:466)
  * accept iff u_acc <= exp(beta*(logL_new-logL)/T).
- * rotate is a mask of MHD_ROT_*.  sample_prior != 0 skips the forward model
+ * rotate is a mask of MHD_ROT_* and MHD_PROPOSE_UNIFORM.  sample_prior != 0 skips the forward model
  * and uses logL_new = 1 (model.py:234-236).
  * Optional outputs (NULL to skip): accepted[S,B] (uint8), status[S,B],
  * hist_m[S/hist_every,B,NP], hist_logL[S/hist_every,B], hist_pred[S/hist_every,B,ND]

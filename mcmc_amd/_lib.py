@@ -17,9 +17,9 @@ ST_OK, ST_BOUNDS, ST_PHYSICS, ST_NOROOT, ST_ZERODIV = 0, 1, 2, 3, 4
 RAYLEIGH, LOVE = 0, 1
 PHASE, GROUP, PHASE_AND_GROUP, PHASE_AND_ELL, ELL = 0, 1, 2, 3, 4
 NORMAL, ASYM_LAPLACE = 0, 1
-ROT_ACCUMULATE, ROT_FRAME = 1, 2
+ROT_ACCUMULATE, ROT_FRAME, PROPOSE_UNIFORM = 1, 2, 4
 MAX_LAYERS, MAX_PERIODS = 15, 128
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EXPORTS = (
     "mhd_abi_version",

@@ -262,6 +262,7 @@ struct ProposalFrame {
     const double* R;                   // rotation matrix of the chain, or nullptr
     int nl, NP;                        // finite layers of THIS chain; slots of a row
     int nlmax;                         // slot of the first layer's vs = (NP - 1) / 2
+    bool uniform;                      // MHD_PROPOSE_UNIFORM: the draw replaces the parameter
     // the slots this chain's model uses (all of them unless the batch mixes layer counts)
     __device__ bool used(int slot) const
     {
@@ -278,7 +279,9 @@ __device__ inline int propose_wave(const ProposalFrame& f, const double* mn, int
         if (lane < NP) {
             double acc = 0.0;
             for (int j = 0; j < NP; ++j) acc += R[j * NP + lane] * mn[j];
-            if (lane == kk) acc += f.wid[kk] * cz;
+            // model.py:207 sets the (normalised, rotated) parameter to the physical lower bound
+            // plus the draw; model.py:210 adds the scaled Cauchy deviate
+            if (lane == kk) acc = f.uniform ? f.lo[kk] + cz : acc + f.wid[kk] * cz;
             tmp[lane] = acc;
         }
         wave_sync();
@@ -289,7 +292,7 @@ __device__ inline int propose_wave(const ProposalFrame& f, const double* mn, int
         }
     } else if (lane < NP) {
         double v = mn[lane];
-        if (lane == kk) v += f.wid[kk] * cz;
+        if (lane == kk) v = f.uniform ? f.lo[kk] + cz : v + f.wid[kk] * cz;
         test[lane] = (v * f.rg[lane]) + f.lo[lane];
     }
     wave_sync();
@@ -374,7 +377,8 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
     double logL = ch.logL[ib];
     const double beta = ch.beta ? ch.beta[ib] : 1.0;
     const double* R = (rotate & MHD_ROT_FRAME) ? ch.rot + (size_t)ib * NP * NP : nullptr;
-    const ProposalFrame frame = {lo, hi, rg, wid, R, nl, NP, nlmax};
+    const ProposalFrame frame = {lo, hi, rg, wid, R, nl, NP, nlmax,
+                                 (rotate & MHD_PROPOSE_UNIFORM) != 0};
     long long c_acc = 0, c_rej = 0, c_bnd = 0, c_fm = 0;
 #ifdef MHD_PROFILE
     const long long k_t0 = clock64(), k_w0 = wall_clock64();
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred,
                                        scratch, cnt, policy.stepwise(), pred, pred,
-                                       !phase_hint ? 0 : (fabs(cz) <= hlim[kk] ? 2 : 1));
+                                       !phase_hint ? 0 : (!frame.uniform && fabs(cz) <= hlim[kk] ? 2 : 1));
                 if (lane == 0)
                     hint_limit_update(hlim, kk, cz, __builtin_amdgcn_readfirstlane(g_PS.hinted));
                 if (search == 2)
@@ -908,7 +912,8 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     double logL = uniform_value(ch.logL[ib]);
     const double beta = uniform_value(ch.beta ? ch.beta[ib] : 1.0);
     const double* R = (rotate & MHD_ROT_FRAME) ? ch.rot + (size_t)ib * NP * NP : nullptr;
-    const ProposalFrame frame = {lo, hi, rg, wid, R, nl, NP, nlmax};
+    const ProposalFrame frame = {lo, hi, rg, wid, R, nl, NP, nlmax,
+                                 (rotate & MHD_PROPOSE_UNIFORM) != 0};
     int c_acc = 0, c_rej = 0, c_bnd = 0, c_fm = 0;
     unsigned long long lit = 0, exec = 0;
     // evaluation rounds of the forwards of the chain's first candidate (the one that is always
@@ -1135,7 +1140,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
                     break;
                 }
                 if ((mybits >> i) & 1) {
-                    small_moves = small_moves && fabs(czc) <= hlim[kkc];
+                    small_moves = small_moves && !frame.uniform && fabs(czc) <= hlim[kkc];
                     // taken to be accepted: the state moves as the settlement would move it
                     if (lane < NP) {
                         const double mv = frame.used(lane) ? test[w][lane] : cur_m[lane];
@@ -1536,7 +1541,7 @@ int mhd_loglik_batch(const mhd_problem_t* prob, const double* pred, int32_t B, d
 
 static int check_chains(const mhd_chains_t* ch, int rotate, const mhd_problem_t* prob = nullptr)
 {
-    if (prob && prob->n_layers_b && rotate)
+    if (prob && prob->n_layers_b && (rotate & (MHD_ROT_ACCUMULATE | MHD_ROT_FRAME)))
         return fail(MHD_EINVAL, "rotated proposals are not available with n_layers_b");
     if (!ch) return fail(MHD_EINVAL, "chains is NULL");
     if (!ch->m || !ch->logL || !ch->pred || !ch->params_prev || !ch->width || !ch->counters)
@@ -1620,6 +1625,8 @@ static int mh_steps_check(const mhd_problem_t* prob, const mhd_chains_t* chains,
     if (int rc = check_chains(chains, rotate, prob)) return rc;
     if (B < 0 || n_steps < 0 || hist_every < 0) return fail(MHD_EINVAL, "negative size");
     if (!(T > 0.0)) return fail(MHD_EINVAL, "T must be positive");
+    if (rotate & ~(MHD_ROT_ACCUMULATE | MHD_ROT_FRAME | MHD_PROPOSE_UNIFORM))
+        return fail(MHD_EINVAL, "unknown bit in the rotate mask");
     if (diag && diag->hist_counters_ind && !chains->counters_ind)
         return fail(MHD_EINVAL, "hist_counters_ind needs counters_ind");
     if (diag && diag->hist_cov && (!chains->cov_sum || !chains->n_cov))

@@ -259,7 +259,7 @@ class DeviceChains:
             if self.counters_ind is not None:
                 out["hist_counters_ind"] = torch.empty((n, B, NP, 5), **i64)
                 diag.hist_counters_ind = out["hist_counters_ind"].data_ptr()
-            if rotate and self.cov_sum is not None:
+            if (rotate & (L.ROT_ACCUMULATE | L.ROT_FRAME)) and self.cov_sum is not None:
                 out["hist_cov"] = torch.empty((n, B, NP, NP), dtype=torch.float64, device=dev)
                 diag.hist_cov = out["hist_cov"].data_ptr()
         ch = self.struct()

@@ -434,7 +434,8 @@ class Inversion:
                 return a
             return torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
         return self.state.steps(t(idx, torch.int32), t(cauchy, torch.float64),
-                                t(u_acc, torch.float64), T=T, rotate=rotate,
+                                t(u_acc, torch.float64), T=T,
+                                rotate=rotate | getattr(self, "_propose_flag", 0),
                                 sample_prior=sample_prior, hist_every=hist_every,
                                 want_pred_hist=want_pred_hist, want_diag=want_diag)
 
@@ -447,7 +448,9 @@ class Inversion:
             n, nmax = self.layer_counts[None, :], self.model_params.n_layers
             j = np.random.randint(2 * n + 1, size=(S, self.n_local))
             idx = np.where(j < n, j, nmax + j - n).astype(np.int32)
-        cz = np.tan(np.pi * (np.random.uniform(size=(S, self.n_local)) - 0.5))
+        cz = np.random.uniform(size=(S, self.n_local))
+        if not getattr(self, "_propose_flag", 0):
+            cz = np.tan(np.pi * (cz - 0.5))
         xi = np.random.uniform(size=(S, self.n_local))
         return idx, cz, xi
 
@@ -533,10 +536,12 @@ class Inversion:
     def random_walk(self, model_params, proposal_distribution, sample_prior=False,
                     rotate_params=False):
         """The main loop for n_mcmc steps (src/inversion/inversion.py:367-429)."""
-        if proposal_distribution != "cauchy":
-            raise NotImplementedError(
-                "only the 'cauchy' proposal is mirrored; the reference's 'uniform' branch adds a "
-                "physical bound to a normalised value (src/inversion/model.py:207)")
+        # "uniform" is the reference's branch as it stands (src/inversion/model.py:205-207): the
+        # normalised parameter becomes its PHYSICAL lower bound plus a uniform draw; any other
+        # name leaves the proposal unperturbed there and is refused here
+        if proposal_distribution not in ("cauchy", "uniform"):
+            raise ValueError("proposal_distribution must be 'cauchy' or 'uniform'")
+        self._propose_flag = L.PROPOSE_UNIFORM if proposal_distribution == "uniform" else 0
         try:
             if self.tempering:
                 self._random_walk_tempered(rotate_params, sample_prior)

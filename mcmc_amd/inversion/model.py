@@ -104,10 +104,9 @@ class Model:
         the proposal was valid -- the accept uniform.
         """
         import torch
-        if proposal_distribution != "cauchy":
-            raise NotImplementedError(
-                "only the 'cauchy' proposal is mirrored; the reference's 'uniform' branch adds a "
-                "physical bound to a normalised value (src/inversion/model.py:207)")
+        if proposal_distribution not in ("cauchy", "uniform"):
+            raise ValueError("proposal_distribution must be 'cauchy' or 'uniform'")
+        uniform = proposal_distribution == "uniform"
         if linear_rotation:
             self.linear_rotation()
         pb = self.param_bounds
@@ -122,7 +121,11 @@ class Model:
                 self.rotation_matrix, self.proposal_width = self.update_rotation_matrix()
 
         ind = np.random.randint(self.model_params.n_model_params)
-        cz = np.tan(np.pi * (np.random.uniform() - 0.5))
+        # "uniform": the draw itself; the device sets the parameter to its physical lower bound
+        # plus the draw, the reference's arithmetic (src/inversion/model.py:207)
+        cz = np.random.uniform()
+        if not uniform:
+            cz = np.tan(np.pi * (cz - 0.5))
         rng_state = np.random.get_state()
         xi = np.random.uniform()
 
@@ -132,7 +135,8 @@ class Model:
         out = ch.steps(torch.tensor([[ind]], dtype=torch.int32, device=dev),
                        torch.tensor([[cz]], dtype=torch.float64, device=dev),
                        torch.tensor([[xi]], dtype=torch.float64, device=dev), T=float(T),
-                       rotate=(L.ROT_FRAME if (rotate_params and not burn_in) else 0),
+                       rotate=(L.ROT_FRAME if (rotate_params and not burn_in) else 0)
+                       | (L.PROPOSE_UNIFORM if uniform else 0),
                        sample_prior=sample_prior)
         status = int(out["status"][0, 0])
         acc = bool(out["accepted"][0, 0])

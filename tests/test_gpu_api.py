@@ -35,10 +35,12 @@ def test_forward_model_drop_in(oracle):
         pytest.skip("no failing draw found")
 
 
-@pytest.mark.parametrize("case", ["3layer_normal", "3layer_individual_T2", "3layer_rotate"])
+@pytest.mark.parametrize("case", ["3layer_normal", "3layer_individual_T2", "3layer_rotate",
+                                  "3layer_uniform", "3layer_uniform_rotate"])
 def test_model_perturb_params_drop_in(case):
     """Model.perturb_params driven exactly like the reference's: np.random is patched to serve
-    the trace's draws in the order the reference consumes them."""
+    the trace's draws in the order the reference consumes them.  Both proposal distributions
+    of the reference."""
     from mcmc_amd.inversion import Data, Model
     g = load_golden(f"mh_trace_{case}.json")
     nl = g["n_layers"]
@@ -70,7 +72,8 @@ def test_model_perturb_params_drop_in(case):
     try:
         for s, rec in enumerate(g["steps"]):
             n_step, thin = divmod(s, g["n_thin"])
-            model.perturb_params(data, "cauchy", n_step, g["n_burn"], 500, thin, T=g["T"],
+            model.perturb_params(data, g.get("proposal", "cauchy"), n_step, g["n_burn"], 500,
+                                 thin, T=g["T"],
                                  rotate_params=g["rotate"])
             assert f.n == rec["n_uniform_draws"], s
             f.s += 1
@@ -89,9 +92,12 @@ def test_model_perturb_params_drop_in(case):
         np.random.randint, np.random.uniform, np.random.get_state, np.random.set_state = saved
 
 
-def test_inversion_random_walk_matches_oracle(oracle, tmp_path):
-    """Inversion.random_walk on supplied draws: chains, thinning, chunked output."""
+@pytest.mark.parametrize("proposal", ["cauchy", "uniform"])
+def test_inversion_random_walk_matches_oracle(oracle, tmp_path, proposal):
+    """Inversion.random_walk on supplied draws: chains, thinning, chunked output; with either
+    proposal distribution of the reference (any other name is refused)."""
     from mcmc_amd.inversion import Data, Inversion
+    flag = 4 if proposal == "uniform" else 0
     nl, P = 3, 20
     mp = _mp(nl)
     periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
@@ -112,17 +118,21 @@ def test_inversion_random_walk_matches_oracle(oracle, tmp_path):
         drawn.append(d)
         return d
     inv._draws = record
-    inv.random_walk(mp, "cauchy")
+    with pytest.raises(ValueError):
+        inv.random_walk(mp, "normal")
+    inv.random_walk(mp, proposal)
     idx = np.concatenate([d[0] for d in drawn])
     cz = np.concatenate([d[1] for d in drawn])
     xi = np.concatenate([d[2] for d in drawn])
     assert idx.shape == (120, 1)
+    assert (cz >= 0).all() == (proposal == "uniform")   # the draw itself, not its tangent
     _, vel, _ = oracle.forward_batch(start, nl, 1.75, periods)
     st = oracle.ChainState(start, [oracle.loglik(obs, vel[0], "normal", noise)], vel, 0.05,
                            mp.assemble_param_bounds())
     hist = []
     for s in range(120):
-        oracle.mh_step(st, idx[s], cz[s], xi[s], nl, 1.75, periods, obs, "normal", noise)
+        oracle.mh_step(st, idx[s], cz[s], xi[s], nl, 1.75, periods, obs, "normal", noise,
+                       rotate=flag)
         if s % 3 == 2:
             hist.append(st.m[0].copy())
     np.testing.assert_array_equal(inv.state.m.cpu().numpy(), st.m)

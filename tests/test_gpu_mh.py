@@ -23,9 +23,12 @@ def _noise(g):
 
 
 @pytest.mark.parametrize("case", ["3layer_normal", "6layer_normal", "6layer_asymlaplace",
-                                  "3layer_individual_T2", "asymlaplace_WH01"])
+                                  "3layer_individual_T2", "asymlaplace_WH01", "3layer_uniform"])
 def test_reference_trace(case):
+    """Traces of the reference's own Model.perturb_params; 3layer_uniform with its "uniform"
+    proposal (src/inversion/model.py:205-207), the others with the Cauchy one."""
     import torch
+    from mcmc_amd import _lib as L
     from mcmc_amd.engine import DeviceChains, DeviceProblem
     g = load_golden(f"mh_trace_{case}.json")
     nl = g["n_layers"]
@@ -39,9 +42,12 @@ def test_reference_trace(case):
     S = len(g["steps"])
     dev = prob.device
     idx = torch.tensor(np.array(g["idx"], dtype=np.int32)[:, None], device=dev)
-    cauchy = torch.tensor(np.tan(np.pi * (np.array(g["u_prop"]) - 0.5))[:, None], device=dev)
+    uniform = g.get("proposal", "cauchy") == "uniform"
+    draw = np.array(g["u_prop"])
+    cauchy = torch.tensor((draw if uniform else np.tan(np.pi * (draw - 0.5)))[:, None], device=dev)
     u_acc = torch.tensor(np.array(g["u_acc"])[:, None], device=dev)
-    out = ch.steps(idx, cauchy, u_acc, T=g["T"], hist_every=1)
+    out = ch.steps(idx, cauchy, u_acc, T=g["T"], hist_every=1,
+                   rotate=L.PROPOSE_UNIFORM if uniform else 0)
     hist_m = out["hist_m"].cpu().numpy()[:, 0]
     hist_l = out["hist_logL"].cpu().numpy()[:, 0]
     status = out["status"].cpu().numpy()[:, 0]
@@ -66,10 +72,14 @@ def test_reference_trace(case):
     np.testing.assert_array_equal(ch.pred.cpu().numpy()[0], g["final_pred"])
 
 
+@pytest.mark.parametrize("proposal", ["cauchy", "uniform"])
 @pytest.mark.parametrize("n_layers,P,B,S", [(3, 20, 64, 60), (6, 40, 256, 40)])
-def test_batched_steps_vs_oracle(oracle, n_layers, P, B, S):
-    """Many chains from prior draws (includes forward failures and bounds rejections)."""
+def test_batched_steps_vs_oracle(oracle, n_layers, P, B, S, proposal):
+    """Many chains from prior draws (includes forward failures and bounds rejections), with
+    either proposal of the reference."""
     import torch
+    from mcmc_amd import _lib as L
+    flag = L.PROPOSE_UNIFORM if proposal == "uniform" else 0
     from mcmc_amd.engine import DeviceChains, DeviceProblem
     rng = np.random.default_rng(42 + n_layers)
     nl, NP = n_layers, 2 * n_layers + 1
@@ -91,17 +101,19 @@ def test_batched_steps_vs_oracle(oracle, n_layers, P, B, S):
     ologL = np.array([oracle.loglik(obs, v, "normal", noise) for v in ovel])
     ost = oracle.ChainState(starts, ologL, ovel, 0.05, bounds)
     idx = rng.integers(0, NP, (S, B)).astype(np.int32)
-    cauchy = np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5))
+    cauchy = rng.uniform(size=(S, B))
+    if not flag:
+        cauchy = np.tan(np.pi * (cauchy - 0.5))
     u_acc = rng.uniform(size=(S, B))
     dev = prob.device
     out = ch.steps(torch.tensor(idx, device=dev), torch.tensor(cauchy, device=dev),
-                   torch.tensor(u_acc, device=dev))
+                   torch.tensor(u_acc, device=dev), rotate=flag)
     acc = np.zeros((S, B), dtype=np.uint8)
     stat = np.zeros((S, B), dtype=np.int32)
     lit = 0
     for s in range(S):
         acc[s], stat[s], ne = oracle.mh_step(ost, idx[s], cauchy[s], u_acc[s], nl, 1.75, periods,
-                                             obs, "normal", noise, beta=beta)
+                                             obs, "normal", noise, beta=beta, rotate=flag)
         lit += ne
     np.testing.assert_array_equal(out["accepted"].cpu().numpy(), acc)
     np.testing.assert_array_equal(out["status"].cpu().numpy(), stat)

@@ -95,7 +95,9 @@ def _replay(oracle, g):
     noise = {k: (np.array(v) if isinstance(v, list) else v) for k, v in g["noise_params"].items()}
     st = oracle.ChainState(np.array([g["start"]]), [g["start_logL"]], np.array([g["start_pred"]]),
                            g["width0"], g["bounds"])
-    cauchy = np.tan(np.pi * (np.array(g["u_prop"]) - 0.5))
+    uniform = g.get("proposal", "cauchy") == "uniform"
+    # the "uniform" proposal (src/inversion/model.py:205-207) takes the draw as it is
+    cauchy = np.array(g["u_prop"]) if uniform else np.tan(np.pi * (np.array(g["u_prop"]) - 0.5))
     ind = g["individual_acceptance"]
     cnt_ind = np.zeros((4, NP))
     n_thin = g["n_thin"]
@@ -119,7 +121,7 @@ def _replay(oracle, g):
                 rot |= 2
         acc, status, _ = oracle.mh_step(st, [g["idx"][s]], [cauchy[s]], [g["u_acc"][s]], nl, vpvs,
                                         periods, obs, g["noise_dist"], noise, T=g["T"],
-                                        rotate=rot)
+                                        rotate=rot | (4 if uniform else 0))
         k = g["idx"][s]
         cnt_ind[0, k] += acc[0]
         cnt_ind[1, k] += 1 - acc[0]
@@ -136,11 +138,11 @@ def _replay(oracle, g):
 
 @pytest.mark.parametrize("case", ["3layer_normal", "6layer_normal", "6layer_asymlaplace",
                                   "3layer_individual_T2", "asymlaplace_WH01", "3layer_tune",
-                                  "3layer_tune_individual"])
+                                  "3layer_tune_individual", "3layer_uniform"])
 def test_mh_trace_bit_exact(oracle, case):
     """State after every step equals the reference's own Model.perturb_params, bit for bit; in
     the two traces with Model.stepsize_tuning (one rate per chain, one per parameter) the
-    proposal widths as well."""
+    proposal widths as well.  3layer_uniform: the reference's "uniform" proposal."""
     g = load_golden(f"mh_trace_{case}.json")
     n = 0
     widths = set()
@@ -171,10 +173,11 @@ def test_mh_trace_bit_exact(oracle, case):
         assert case != "3layer_tune_individual" or min(widths) < 0.05  # ... and narrowed
 
 
-def test_mh_trace_rotation(oracle):
+@pytest.mark.parametrize("case", ["3layer_rotate", "3layer_uniform_rotate"])
+def test_mh_trace_rotation(oracle, case):
     """Covariance accumulation is bit exact; the rotated proposal (BLAS matvec in the
-    reference) agrees to rounding, so the trace is compared at 1e-9."""
-    g = load_golden("mh_trace_3layer_rotate.json")
+    reference) agrees to rounding, so the trace is compared at 1e-9.  Both proposals."""
+    g = load_golden(f"mh_trace_{case}.json")
     for s, rec, st, acc, status, _ in _replay(oracle, g):
         assert st.n_cov[0] == rec["n_cov"], s
         np.testing.assert_allclose(st.m[0], rec["m"], rtol=1e-9, err_msg=f"step {s}")

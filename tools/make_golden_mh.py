@@ -113,7 +113,9 @@ class DrawFeeder:
 
 def run_case(name, n_layers, bounds, periods, true_m, noise_dist, noise_params, n_steps, seed,
              rotate=False, n_burn=0, n_cov_chunk=200, n_thin=1, individual=False, start=None,
-             T=1, tune_every=0):
+             T=1, tune_every=0, proposal="cauchy"):
+    if ONLY and name not in ONLY:
+        return
     vpvs = 1.75
     rng = np.random.default_rng(seed)
     mp = DispersionCurveParams(n_layers, bounds, {"depth": 0.05, "vel_s": 0.05}, vpvs)
@@ -153,7 +155,7 @@ def run_case(name, n_layers, bounds, periods, true_m, noise_dist, noise_params, 
     try:
         for s in range(n_steps):
             for t in range(n_thin):
-                model.perturb_params(data, "cauchy", s, n_burn, 500, t, T=T, rotate_params=rotate)
+                model.perturb_params(data, proposal, s, n_burn, 500, t, T=T, rotate_params=rotate)
                 used = feeder.next_step()
                 # acceptance-rate step-size tuning (src/inversion/model.py:538-556; the reference's
                 # own call, after every step, is commented out at :257): here after every
@@ -201,6 +203,7 @@ def run_case(name, n_layers, bounds, periods, true_m, noise_dist, noise_params, 
         "individual_acceptance": bool(individual),
         "T": T,
         "tune_every": tune_every,
+        "proposal": proposal,
         "idx": idx.tolist(),
         "u_prop": u_prop.tolist(),
         "u_acc": u_acc.tolist(),
@@ -268,6 +271,9 @@ def misc_fixture():
     print("->", path)
 
 
+ONLY = set(sys.argv[1:])  # case names to (re)generate; all when none is given
+
+
 def main():
     p20 = np.flip(1 / np.logspace(0.3, 1.3, 20)).copy()
     p40 = np.flip(1 / np.logspace(0.3, 1.3, 40)).copy()
@@ -296,6 +302,13 @@ def main():
              "normal", {"std": 0.025}, n_steps=300, seed=11, tune_every=25)
     run_case("3layer_tune_individual", 3, b3, p20, [0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0],
              "normal", {"std": 0.025}, n_steps=400, seed=12, individual=True, tune_every=40)
+    # the reference's "uniform" proposal as it stands (src/inversion/model.py:205-207: physical
+    # lower bound + U(0,1) in normalised coordinates), plain and in the rotated frame
+    run_case("3layer_uniform", 3, b3, p20, [0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0],
+             "normal", {"std": 0.025}, n_steps=400, seed=21, proposal="uniform")
+    run_case("3layer_uniform_rotate", 3, b3, p20, [0.02, 0.04, 0.07, 0.2, 0.4, 0.6, 1.0],
+             "normal", {"std": 0.025}, n_steps=60, seed=22, rotate=True, n_burn=10, n_cov_chunk=5,
+             n_thin=2, proposal="uniform")
     # the reference's one working configuration (src/main.py:380-407 -> :261-347): two layers,
     # asymmetric-Laplace likelihood, the 60 periods and per-period lambda scaling of site WH01
     # (flipped, clipped at 60: src/main.py:313-317), lambd = 1, kappa = 0.75, bounds of
@@ -310,7 +323,8 @@ def main():
     run_case("asymlaplace_WH01", 2, b2, np.flip(1 / df["freqs"].values).copy(), wh01_true,
              "asym-laplace", {"lambd_scale": lam_scale, "lambd": 1.0, "kappa": 0.75},
              n_steps=400, seed=6, start=wh01_true)
-    misc_fixture()
+    if not ONLY:
+        misc_fixture()
 
 
 if __name__ == "__main__":
