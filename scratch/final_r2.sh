@@ -1,5 +1,5 @@
 #!/bin/bash
-# the measurements DESIGN.md quotes, into gpurun_out/final: bench lines, variants, trajectory averages
+# the measurements kept under profiles/ (r2_*), into gpurun_out/final: bench lines, variants, trajectory averages
 set -o pipefail
 out=gpurun_out/final; mkdir -p $out
 timeout -k 10 400 python bench.py > $out/bench.json 2> $out/bench.err || exit 1

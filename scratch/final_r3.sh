@@ -1,5 +1,5 @@
 #!/bin/bash
-# the measurements DESIGN.md quotes for round 3, into gpurun_out/final_r3: bench lines, the
+# the measurements kept under profiles/ (r3_*), into gpurun_out/final_r3: bench lines, the
 # two-rank rehearsal (both ranks on the one GPU, gloo standing in for RCCL), variants, trajectory
 # averages, repeats of the driver's command
 set -o pipefail
