@@ -220,6 +220,7 @@ class Inversion:
         if record_diagnostics not in ("chunk", "step", "full"):
             raise ValueError("record_diagnostics must be 'chunk', 'step' or 'full'")
         self.record_diagnostics = record_diagnostics
+        self._propose_flag = 0  # L.PROPOSE_UNIFORM while random_walk runs the "uniform" proposal
         self.async_sink = bool(async_sink)
         # temperature ladders: the reference's flat ladder over all chains, or n_chains ladders
         if n_temps is None:
@@ -435,7 +436,7 @@ class Inversion:
             return torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
         return self.state.steps(t(idx, torch.int32), t(cauchy, torch.float64),
                                 t(u_acc, torch.float64), T=T,
-                                rotate=rotate | getattr(self, "_propose_flag", 0),
+                                rotate=rotate | self._propose_flag,
                                 sample_prior=sample_prior, hist_every=hist_every,
                                 want_pred_hist=want_pred_hist, want_diag=want_diag)
 
@@ -449,7 +450,7 @@ class Inversion:
             j = np.random.randint(2 * n + 1, size=(S, self.n_local))
             idx = np.where(j < n, j, nmax + j - n).astype(np.int32)
         cz = np.random.uniform(size=(S, self.n_local))
-        if not getattr(self, "_propose_flag", 0):
+        if not self._propose_flag:
             cz = np.tan(np.pi * (cz - 0.5))
         xi = np.random.uniform(size=(S, self.n_local))
         return idx, cz, xi
