@@ -8,17 +8,15 @@
  * Conventions
  *   - every pointer marked "device" is caller-owned HBM (for example
  *     torch.Tensor.data_ptr()); the library allocates no device memory and never
- *     frees.  What it does create, once per device and kept until the process
- *     ends, is one extra stream and two events (mhd_init);
+ *     frees, and creates no stream or event: every launch of a call goes to the
+ *     caller's stream;
  *   - all arrays are dense row-major, float64 unless stated;
  *   - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL
  *     is the default stream) and return 0 or a negative MHD_E* code;
  *     mhd_last_error() gives the text of the last failure on this thread;
- *   - threads: any number of host threads may call into the library; calls of
- *     mhd_mh_steps that use the launch schedule (mhd_chains_t.sched) are
- *     serialised per device while they enqueue their launches.  Two calls that
- *     work on the same chains, or on the same `sched`, must be ordered by the
- *     caller (same stream, or events);
+ *   - threads: any number of host threads may call into the library.  Two calls
+ *     that work on the same chains, or on the same `sched`, must be ordered by
+ *     the caller (same stream, or events);
  *   - per-chain outcome codes (`status`) map onto the reference's counters:
  *       MHD_ST_OK       proposal evaluated
  *       MHD_ST_BOUNDS   n_bounds_err   (src/inversion/model.py:110-117)
@@ -163,10 +161,11 @@ typedef struct mhd_chains {
                             proposals it accepted) and within one (how far
                             each chain has got); zero it once, before the first
                             call.  It is used by calls with 64 <= B <= 4096 chains,
-                            candidates = 0 or 2 and sample_prior = 0: the chains
-                            that take longest get four candidates from the start,
-                            and a call of at least mhd_sched_min_steps() steps is
-                            two launches, the first ending at a deadline, the second
+                            candidates = 0 or 2 and sample_prior = 0: the few chains
+                            that take longest get four candidates from the start
+                            (as many of the cheapest ones one instead of two), and
+                            a call of at least mhd_sched_min_steps() steps is two
+                            launches, the first ending at a deadline, the second
                             giving the chains that are behind more candidates in
                             flight (a shorter call is one launch).  Results do not
                             depend on it; no counterpart in the reference */
@@ -202,13 +201,13 @@ int mhd_abi_version(void);
 const char *mhd_last_error(void);
 
 /*
- * Per-device set-up: the second stream and the two events that tie it to the
- * caller's stream in scheduled calls of mhd_mh_steps, and the address of the
- * library's static device scratch (mhd_mh_steps_static).  device < 0 means the
- * current device.  Thread-safe; a second call for the same device does nothing.
+ * Per-device set-up: the number of compute units (scheduled calls of
+ * mhd_mh_steps size their launches by it) and the address of the library's
+ * static device scratch (mhd_mh_steps_static).  device < 0 means the current
+ * device.  Thread-safe; a second call for the same device does nothing.
  * mhd_mh_steps calls it at its first scheduled call on a device if the caller
- * has not; callers that must not create streams or events later (graph capture,
- * serving loops) call it once at start-up.  No counterpart in the reference.
+ * has not; mhd_mh_steps_static requires it to have been called.  It creates no
+ * stream, event or memory.  No counterpart in the reference.
  */
 int mhd_init(int32_t device);
 

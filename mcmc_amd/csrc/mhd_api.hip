@@ -555,22 +555,25 @@ __global__ __launch_bounds__(256) void stepsize_tuning_kernel(mhd_chains_t ch, i
 // of its forwards it accepted lately.  Only the deadline of a launch needs the clock: the ticks
 // of the 100 MHz counter that one evaluation round took on average in the launch before (one
 // number for all chains, summed in the header).
-// The launch is made from the chains in order of decreasing expected time and the number n4 of
-// chains at the head of that order that run with four candidates in flight.  Somewhat more than
-// 2 * n4 chains at its tail run with one candidate, all others with two, so a launch keeps at
-// most two waves per chain on average and the expensive chains finish closer to the others.
+// The launch is made from the chains in order of decreasing expected time: the n4 chains at the
+// head of that order run with four candidates in flight, the 4 * n1 = 2 * n4 chains at its tail
+// with one, all others with two, so a launch keeps two waves per chain on average, and the
+// expensive chains finish closer to the others.  Every workgroup has four waves, whatever it
+// holds, so the launch fills the wave slots exactly whichever way the chains are split.
 constexpr int SCHED_MAX_CHAINS = 4096;  // one workgroup sorts them in LDS
 constexpr int SCHED_MIN_CHAINS = 64;    // fewer chains leave the GPU empty however they are ordered
-// a chain gets four candidates when with two it is expected to take longer than this fraction of
-// the time of the most expensive chain with four (the estimates are some 10 % uncertain)
-#ifndef SCHED_MARGIN
-#define SCHED_MARGIN 0.85f
+// in a call's first launch a chain gets four candidates when with two it is expected to take
+// longer than this multiple of the median chain's time; at most SCHED_FOUR_MAX(B) chains do
+// (measured with 1024 chains: thresholds 1.15 ... 1.3 and 2 ... 8 chains are within 1 % of each
+// other, 16 and more cost what they gain)
+#ifndef SCHED_FOUR_ABOVE
+#define SCHED_FOUR_ABOVE 1.2f
+#endif
+#ifndef SCHED_FOUR_MAX
+#define SCHED_FOUR_MAX(B) ((B) / 256 > 2 ? (B) / 256 : 2)
 #endif
 #ifndef SCHED_GAIN
 #define SCHED_GAIN 0.5f
-#endif
-#ifndef SCHED_SPARE_N
-#define SCHED_SPARE_N 64
 #endif
 // share of a chain's steps that have a forward model, before the chain has shown its own
 #ifndef SCHED_PVALID_PRIOR
@@ -582,7 +585,6 @@ constexpr int SCHED_MIN_CHAINS = 64;    // fewer chains leave the GPU empty howe
 #ifndef SCHED_COST_PRIOR
 #define SCHED_COST_PRIOR 20.0f  // evaluation rounds per step of a chain that has not run a forward yet
 #endif
-constexpr int SCHED_SPARE = SCHED_SPARE_N;           // workgroup places left free in a scheduled launch
 #ifndef SPEC_FIRST_A
 #define SPEC_FIRST_A 0.42f
 #endif
@@ -602,7 +604,7 @@ __host__ __device__ inline float sched_consumed(int nw, float p)
 
 struct SchedView {
     float* cost;  // [B]
-    int* n4;      // [0] n4, [1] number of split workgroups, [2..3] the deadline of the launch,
+    int* n4;      // [0] n4, [1] n1: workgroups of four one-candidate chains, [2..3] the deadline of the launch,
                   // [4] n4 of the call's first launch, [5] chains the last launch found unfinished
                   // (diagnostics), [6..7] as floats: ticks and evaluation rounds of the launches
                   // since the last phase 0 (their ratio prices a round for the deadlines)
@@ -705,33 +707,33 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
             __syncthreads();
         }
     }
-    // four candidates for the chains that would otherwise finish later than the most expensive
-    // one does with four -- as long as the chains that give up a candidate for it still finish
-    // earlier than that.  A few more chains than needed give one up: workgroups do not pack
-    // perfectly, and one that has to wait for room starts when the first chains are done.
+    // the candidates of the launch
     if (threadIdx.x == 0) {
-        int n4 = 0, nsplit = 0;
+        int n4 = 0, n1 = 0;
         unsigned long long deadline = 0;
         // what an evaluation round took lately, in ticks (0: not known, no deadline)
         float* calib = (float*)(v.n4 + 6);
         const float tick = calib[1] > 0.0f ? calib[0] / calib[1] : 0.0f;
-        // the same chain's expected rounds per step with four candidates, with one
+        // the same chain's expected rounds per step with four candidates
         auto with_four = [&](int j) {
             const float p = sched_pacc(v, val[j]);
             return key[j] * sched_consumed(2, p) / sched_consumed(4, p);
         };
-        auto with_one = [&](int j) { return key[j] * sched_consumed(2, sched_pacc(v, val[j])); };
         if (!unknown && phase == 0) {
-            const float with4 = with_four(0);
+            // four candidates for the chains that stand out from the others; each takes two
+            // wave slots more, which two of the cheapest chains give up
             const int cap = sched_cap4(B, 0);
-            while (n4 < cap && key[n4] > SCHED_MARGIN * with4) {
-                const int ns = n4 + 1 + SCHED_SPARE + (n4 + 1) / 2;
-                if (n4 + 1 + 2 * ns >= B) break;
-                const float target = fmaxf(with4, key[n4 + 1]);
-                if (with_one(B - 2 * ns) > target) break;
+#ifdef MHD_ABORT_SABOTAGE
+            const bool whatever_they_cost = true;  // the test build runs every kind of workgroup
+#else
+            const bool whatever_they_cost = false;
+#endif
+            // (with more chains than the GPU holds at once the launch is a queue of
+            // two-candidate workgroups in this order: whoever finishes makes room)
+            while (2 * B <= slots && n4 < cap && n4 < SCHED_FOUR_MAX(B) && 4 * n4 + 8 < B &&
+                   (whatever_they_cost || key[n4] > SCHED_FOUR_ABOVE * key[B / 2]))
                 ++n4;
-                nsplit = ns;
-            }
+            n1 = (n4 + 1) / 2;
             if (PHASE_DEADLINE_FRACTION > 0.0f && phases > 1 && tick > 0.0f)
                 deadline = (unsigned long long)wall_clock64() +
                            (unsigned long long)(PHASE_DEADLINE_FRACTION * key[B / 2] * (float)S *
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
             int left = 0;
             while (left < B && key[left] > 0.0f) ++left;
             v.n4[5] = left;
-            const int room = (slots - 2 * left) / 2;
+            const int room = 2 * B > slots ? 0 : (slots - 2 * left) / 2;
             n4 = room < 0 ? 0 : (room < left ? room : left);
             const int cap = sched_cap4(B, phase);
             if (n4 > cap) n4 = cap;
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
                                                                : key[left / 2]));
         }
         v.n4[0] = n4;
-        v.n4[1] = nsplit;
+        v.n4[1] = n1;
         if (phase == 0) v.n4[4] = n4;
         v.n4[2] = (int)(deadline & 0xFFFFFFFFull);
         v.n4[3] = (int)(deadline >> 32);
@@ -771,10 +773,8 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
 // state the sequential chain has at that step.  States, likelihoods, counters and the draw each
 // step consumes are those of the one-candidate kernel.
 //
-// scheduled: the workgroups take their chains from the launch schedule (see SchedView): the
-// NW = 4 kernel the n4 most expensive chains, the NW = 2 kernel all others -- the 2 * n4
-// cheapest ones two to a workgroup, each with ONE wave and one candidate ("split" workgroups,
-// whose two waves never meet in a barrier).
+// scheduled (NW = 4): the workgroups take their chains from the launch schedule (see SchedView)
+// and hold one chain with four candidates, two with two each or four with one each.
 #ifndef ABORT_MOOT
 #define ABORT_MOOT 1
 #endif
@@ -825,8 +825,10 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     int hist_every, double* hist_m, double* hist_logL, double* hist_pred, mhd_diag_t dg,
     unsigned long long* n_evals, int search, int scheduled)
 {
-    constexpr int NG = (NW == 2) ? 2 : 1;  // chains a workgroup can hold
+    constexpr int NG = (NW == 4) ? 4 : 1;  // chains a workgroup can hold (a scheduled launch
+                                           // packs one, two or four into a workgroup of four waves)
     __shared__ long long cbase_[NG][5];    // the chain's counters when the launch starts
+    __shared__ unsigned pair_arrivals[2];  // see pair_sync
     __shared__ double lo[MAXNP], hi[MAXNP], rg[MAXNP];
     __shared__ double t[MAXP];
     __shared__ double m_[NG][MAXNP];    // current parameters
@@ -849,32 +851,72 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     // (wave-uniform values are moved to scalar registers explicitly: what the compiler cannot
     // prove uniform it keeps per lane, and those registers are spilled around every forward)
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    // the chain of this wave: the workgroup's own index, or its place in the launch schedule
+    // the chain of this wave: the workgroup's own index, or its place in the launch schedule.
+    // A scheduled launch (NW = 4 only) is made of workgroups of one size: the n4 most expensive
+    // chains have one to themselves (four candidates), the 4 * n1 cheapest ones sit four to a
+    // workgroup (one wave, one candidate each), all others two to a workgroup (two candidates
+    // each); a workgroup's chains meet in no barrier but the one below.
     int ib = blockIdx.x;
-    bool split = false;
-    if (scheduled) {
+    int g = 0, w0 = 0, nw = NW;  // chain slot in the workgroup, the chain's first wave, its waves
+    bool idle = false;           // nothing for this wave in this launch
+    if (NW == 4 && scheduled) {
         const SchedView sv = sched_view(ch.sched, B);
-        const int n4 = sv.n4[0];
-        if (NW == 4) {
-            if (ib >= n4) return;
+        const int n4 = sv.n4[0], n1 = sv.n4[1];
+        const int pairs = B - n4 - 4 * n1;  // chains that run with two candidates
+        const int np = (pairs + 1) >> 1;    // their workgroups
+        int slot = ib;                      // the chain's place in the launch order
+        if (ib < n4) {
+        } else if (ib < n4 + np) {
+            g = w >> 1;
+            w0 = 2 * g;
+            nw = 2;
+            slot = n4 + 2 * (ib - n4) + g;
+            idle = slot >= n4 + pairs;
+        } else if (ib < n4 + np + n1) {
+            g = w;
+            w0 = w;
+            nw = 1;
+            slot = n4 + pairs + 4 * (ib - n4 - np) + w;
         } else {
-            // first the split workgroups (which run longest), then the others by decreasing
-            // cost: should a few workgroups have to wait for room, they are the cheapest
-            const int nsplit = sv.n4[1];
-            if (ib >= B - n4 - nsplit) return;
-            split = ib < nsplit;
-            ib = split ? B - 2 * nsplit + 2 * ib + w : n4 + ib - nsplit;
+            idle = true;
         }
-        ib = __builtin_amdgcn_readfirstlane(sv.order[ib]);
-        // nothing left of this call for the chain (a later phase): the workgroup is done
-        if (!split && sv.progress[ib] >= S) return;
+        if (!idle) {
+            ib = __builtin_amdgcn_readfirstlane(sv.order[slot]);
+            // nothing left of this call for the chain (a later phase)
+            idle = sv.progress[ib] >= S;
+        }
+        if (idle) ib = 0;
     }
-    const int g = split ? w : 0;    // chain slot of this wave in the workgroup
-    const int w0 = split ? w : 0;   // first wave of this wave's chain
-    const int nw = split ? 1 : NW;  // waves (= candidates in flight) of this wave's chain
+    if (NW == 2 && scheduled) {
+        // more chains than the GPU holds at once: a workgroup each, the expensive ones first
+        const SchedView sv = sched_view(ch.sched, B);
+        ib = __builtin_amdgcn_readfirstlane(sv.order[ib]);
+        idle = sv.progress[ib] >= S;
+    }
     const bool writer = (w == w0);
+    // The waves of a chain meet after every round: all waves of the workgroup in its barrier,
+    // two of its four by counting arrivals in LDS (pair_sync), one alone not at all.
+    unsigned pair_target = 0;
+    auto pair_sync = [&]() {
+        pair_target += 2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0)
+            __hip_atomic_fetch_add(&pair_arrivals[g], 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (both waves are resident, so the other one arrives; the limit -- some ten seconds --
+        // only keeps a defect from hanging the GPU: results are then wrong, not late)
+        for (unsigned spins = 0; spins < (1u << 27); ++spins) {
+            const unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
+                &pair_arrivals[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if ((int)(seen - pair_target) >= 0) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
     auto group_sync = [&]() {
-        if (split) wave_sync(); else __syncthreads();
+        if (nw == 1) wave_sync();
+        else if (nw == NW) __syncthreads();
+        else pair_sync();
     };
     double* m = m_[g];
     double* mn = mn_[g];
@@ -898,7 +940,9 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         rg[threadIdx.x] = p.bounds[3 * threadIdx.x + 2];
     }
     for (int k = threadIdx.x; k < P; k += 64 * NW) t[k] = p.periods[k];
-    __syncthreads();  // the only barrier the waves of a split workgroup share
+    if (threadIdx.x < 2) pair_arrivals[threadIdx.x] = 0u;
+    __syncthreads();  // the only barrier that chains sharing a workgroup share
+    if (idle) return;
     if (writer) {
         if (lane < NP) {
             m[lane] = ch.m[(size_t)ib * NP + lane];
@@ -1092,9 +1136,14 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         // acceptance is poorer for each: such candidates have to be likelier to be worth it)
         const float psel = ABORT_SABOTAGE ? 0.2f + 0.25f * (float)(round_no & 3)
                                           : pacc - (group_kind ? SPEC_GROUP_PENALTY : 0.0f);
-        if (NW == 2) {
+        if (NW == 2 || nw <= 2) {
             nlen[1] = 1;
             nbits[1] = (SPEC_TREE && psel > 0.5f + SPEC_BIAS) ? 1 : 0;
+#pragma unroll
+            for (int q = 2; q < NW; ++q) {
+                nlen[q] = 0;
+                nbits[q] = 0;
+            }
         } else {
             const int kind = !SPEC_TREE ? 0 : (psel < SPEC_FIRST_A ? 0 : (psel < 0.5f + SPEC_BIAS ? 1 : (psel < 0.68f + SPEC_BIAS ? 2 : 3)));
             // kind 0: R RR RRR   1: R RR A   2: A R AA   3: A AA AAA
@@ -1285,7 +1334,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     if (writer && lane == 0 && ib < 1024 && s_begin == 0)
         g_times[2 * (1024 + ib) + 1] = ((unsigned long long)s << 48) |
                                        (((unsigned long long)(wall_clock64() - t_begin) & 0xFFFFFFFFull) << 12) |
-                                       ((unsigned long long)NW << 4) | ((unsigned long long)split << 3) | (unsigned long long)nw;
+                                       ((unsigned long long)NW << 4) | ((unsigned long long)(nw == 1) << 3) | (unsigned long long)nw;
 #endif
     if (writer && lane == 0 && keeps) {
         {
@@ -1357,15 +1406,13 @@ static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 
 namespace {
 
-// What the library keeps per device, made by mhd_init() and kept until the process ends: a
-// second stream for the two-candidate kernel of a scheduled call with the events that tie it to
-// the caller's stream, and the number of compute units.  `mu` serialises the set-up and the
-// fork / launch / join sequence of scheduled calls (the events are shared).
+// What the library keeps per device, made by mhd_init() and kept until the process ends: the
+// number of compute units and the address of the static scratch.  `mu` serialises the set-up
+// and, for mhd_mh_steps_static, the decision whose chains the scratch belongs to with the
+// launches that follow it.
 struct DeviceState {
     std::mutex mu;
     bool ready = false;
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
     int cus = 0;
     void* scratch = nullptr;              // this device's copy of `scratch` (mhd_mh_steps_static)
     int scratch_B = -1;                   // what the scratch was last laid out for: chains ...
@@ -1399,9 +1446,6 @@ DeviceState* device_state(int device, bool create)
         return nullptr;
     }
     if (device != cur) e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipDeviceGetAttribute(&sd.cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) e = hipGetSymbolAddress(&sd.scratch, HIP_SYMBOL(scratch));
@@ -1552,9 +1596,8 @@ static int check_chains(const mhd_chains_t* ch, int rotate, const mhd_problem_t*
     return MHD_OK;
 }
 
-// The launches of one mhd_mh_steps call, for checked arguments.  sd: the per-device state when
-// the call may use the launch schedule (then sd->mu is held by the caller: the fork / join events
-// are shared by the callers of a device, one call enqueues at a time), else nullptr.
+// The launches of one mhd_mh_steps call, for checked arguments, all on the caller's stream.
+// sd: the per-device state when the call uses the launch schedule, else nullptr.
 static int mh_steps_enqueue(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t B,
                             int32_t n_steps, const int32_t* idx, const double* cauchy,
                             const double* u_acc, double T, int32_t rotate, int32_t sample_prior,
@@ -1566,28 +1609,30 @@ static int mh_steps_enqueue(const mhd_problem_t* prob, const mhd_chains_t* chain
     const int search = prob->search ? prob->search : 2;
     const int candidates = prob->candidates ? prob->candidates : 2;
     if (sd) {
-        // the most expensive chains with four candidates (first, so that they are resident when
-        // the others fill the GPU), the others beside them on a second stream
+        // one launch per phase, of workgroups of four waves that hold one, two or four chains
+        // (schedule_kernel says which); the grid covers the most workgroups a phase can need,
+        // those beyond what it does need return at once
         const int slots = sd->cus * 8;  // two waves of these kernels per SIMD
         // (a short call is one launch, see SCHED_MIN_STEPS)
         const int phases = n_steps >= SCHED_PHASES_MIN_STEPS ? SCHED_PHASES : 1;
         for (int phase = 0; phase < phases; ++phase) {
             hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, chains->sched, B,
                                n_steps, phase, phases, slots);
-            hipError_t e = hipEventRecord(sd->fork, s);
-            if (e == hipSuccess) e = hipStreamWaitEvent(sd->stream, sd->fork, 0);
-            if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps fork");
-            hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(sched_cap4(B, phase)), dim3(256),
+            if (2 * B > slots) {
+                // more chains than fit at once: a queue of two-candidate workgroups, one chain
+                // each (a workgroup of two chains would keep its place until both are done)
+                hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128),
+                                   2 * WAVE_LDS_BYTES, s, *prob, *chains, B, n_steps, idx, cauchy,
+                                   u_acc, T, rotate, accepted, status, hist_every, hist_m,
+                                   hist_logL, hist_pred, dg, ne, search, 1);
+                continue;
+            }
+            const int cap = sched_cap4(B, phase);
+            const int grid = phase == 0 ? B / 2 + 2 : cap + (B - cap + 1) / 2 + 1;
+            hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(grid), dim3(256),
                                4 * WAVE_LDS_BYTES, s, *prob, *chains, B, n_steps, idx, cauchy,
                                u_acc, T, rotate, accepted, status, hist_every, hist_m, hist_logL,
                                hist_pred, dg, ne, search, 1);
-            hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES,
-                               sd->stream, *prob, *chains, B, n_steps, idx, cauchy, u_acc, T,
-                               rotate, accepted, status, hist_every, hist_m, hist_logL, hist_pred,
-                               dg, ne, search, 1);
-            e = hipEventRecord(sd->join, sd->stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(s, sd->join, 0);
-            if (e != hipSuccess) return hip_fail(e, "mhd_mh_steps join");
         }
     } else if (candidates == 2 && !sample_prior) {
         hipLaunchKernelGGL(mh_steps_multi_kernel<2>, dim3(B), dim3(128), 2 * WAVE_LDS_BYTES, s,
@@ -1654,7 +1699,6 @@ int mhd_mh_steps(const mhd_problem_t* prob, const mhd_chains_t* chains, int32_t 
                                 hist_pred, dg, n_evals, (hipStream_t)stream, nullptr);
     DeviceState* sd = device_state(-1, true);
     if (!sd) return MHD_EHIP;
-    std::lock_guard<std::mutex> lock(sd->mu);
     return mh_steps_enqueue(prob, chains, B, n_steps, idx, cauchy, u_acc, T, rotate, sample_prior,
                             accepted, status, hist_every, hist_m, hist_logL, hist_pred, dg,
                             n_evals, (hipStream_t)stream, sd);

@@ -91,13 +91,18 @@ def ladder_layout(n_temps, n_ladders, layout):
 def all_gather_blocks(out, local):
     """out[r * n:(r + 1) * n] = rank r's `local` (n values) for every rank: the one collective of
     the sampler, used for the per-replica logL of a tempering sweep.  RCCL ("nccl") on GPUs
-    works in the order of the current stream; any other backend (gloo, in rehearsals and
-    tests) reads the memory from the host, so the stream that produces `local` is waited for
-    first."""
+    works on the device tensors in the order of the current stream.  Any other backend (gloo,
+    in rehearsals and tests, where the ranks may share a GPU) gets host copies: the download
+    waits for the stream that produces `local`, the collective runs on host memory, and the
+    result is uploaded (gloo's own staging of device tensors stopped answering in two of some
+    thirty runs with two processes on one GPU, both ranks inside the collective)."""
     import torch
     import torch.distributed as dist
     if local.is_cuda and dist.get_backend() != "nccl":
-        torch.cuda.current_stream(local.device).synchronize()
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.cpu())
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, local)
     return out
 

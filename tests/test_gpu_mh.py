@@ -293,6 +293,50 @@ def test_scheduled_launches_do_not_change_the_chains(oracle, candidates):
     assert n4_seen > 0   # the schedule really gave some chains four candidates
 
 
+def test_scheduled_launch_of_more_chains_than_fit_at_once(oracle, candidates):
+    """1100 chains are more than a GPU of 256 compute units holds at once with two waves each:
+    such a call is a queue of one-chain workgroups in the order of the schedule (a workgroup of
+    two chains would keep its place until both are done).  Same chains as without the schedule."""
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    if candidates != 2:
+        pytest.skip("scheduling applies to the default number of candidates")
+    rng = np.random.default_rng(19)
+    nl, P, B, S = 3, 12, 1100, 60
+    NP = 2 * nl + 1
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
+    prob0 = DeviceProblem(nl, 1.75, periods)
+    starts = np.empty((0, NP))
+    while starts.shape[0] < B:
+        cand = np.array([oracle.sort_layers(x, nl)
+                         for x in rng.uniform(bounds[:, 0], bounds[:, 1], size=(B, NP))])
+        _, st = prob0.forward(torch.tensor(cand, device=prob0.device))
+        starts = np.concatenate([starts, cand[st.cpu().numpy() == 0]])
+    starts = starts[:B]
+    obs = oracle.forward(starts[0], nl, 1.75, periods)[1] + 0.025 * rng.standard_normal(P)
+    prob = DeviceProblem(nl, 1.75, periods, obs, "normal", {"std": 0.025}, bounds)
+    dev = prob.device
+    idx = torch.tensor(rng.integers(0, NP, (S, B)).astype(np.int32), device=dev)
+    cauchy = torch.tensor(np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5)), device=dev)
+    u_acc = torch.tensor(rng.uniform(size=(S, B)), device=dev)
+    results = []
+    for scheduled in (True, False):
+        ch = DeviceChains(prob, starts, 0.05)
+        if not scheduled:
+            ch.sched = None
+        assert int((ch.init_likelihood() != 0).sum()) == 0
+        acc = []
+        for a in range(0, S, 30):   # the second call knows the costs and is made of two launches
+            acc.append(ch.steps(idx[a:a + 30], cauchy[a:a + 30], u_acc[a:a + 30])["accepted"])
+        results.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(),
+                        torch.cat(acc), int(ch.n_evals[0])))
+    a, b = results
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+    assert a[5] == b[5]
+
+
 def test_scheduled_rotated_launches_do_not_change_the_chains(oracle, candidates):
     """The deadline of a scheduled call cuts chains between two steps of rotated-frame proposals
     with covariance accumulation: the second launch must go on exactly there (cov_sum, n_cov,
