@@ -233,6 +233,29 @@ __device__ __forceinline__ void hint_limit_update(float* limit, int kk, double c
 #ifndef HINTED_TROUBLE_MIN
 #define HINTED_TROUBLE_MIN 3
 #endif
+// Chains in models whose modes lie closer together than the search's step at short periods: the
+// sequential search hops between branches there and every prediction of it costs a repair.  When
+// the curves of a chain's first candidate have needed more than DENSE_REPAIRS_UP repairs each on
+// average lately (one or two chains in a thousand do; the 99th percentile is 0.6), the chain's
+// curves start with DENSE_PREFIX(P) periods by the deferring sequential search and are predicted
+// from there on, for DENSE_HOLD forwards; then the plain predictor is tried again.  (The one
+// such chain among the benchmark's 1024 needs 2.3 repairs per curve, most of them in the first
+// half of the periods, and was the last to finish every call by a fifth of the call's length;
+// with this it finishes among the others.  Measured: 1000-step runs +13 %, 800-step +6 %,
+// eight runs of 1500 ... 3000 steps +1 %, calls of 20 steps unchanged; a threshold of 1.5 with
+// an average over 16 curves lets ordinary chains in now and then and gains nothing.)
+#ifndef DENSE_REPAIRS_UP
+#define DENSE_REPAIRS_UP 1.8f
+#endif
+#ifndef DENSE_HOLD
+#define DENSE_HOLD 64
+#endif
+#ifndef DENSE_PREFIX
+#define DENSE_PREFIX(P) ((P) / 2)
+#endif
+#ifndef DENSE_WINDOW
+#define DENSE_WINDOW 32.0f
+#endif
 struct SearchPolicy {
     int level, left;
     int max_level;  // 3, or 0 where the predictor has the chain's current curve to go by: there
@@ -465,8 +488,12 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
 
 #ifdef MHD_PROFILE
     if (lane == 0) {
+#ifdef MHD_PROFILE_STAGES
         atomicAdd(&g_prof[9], (unsigned long long)(clock64() - k_t0));
         atomicAdd(&g_prof[10], (unsigned long long)(wall_clock64() - k_w0));
+#else
+        (void)k_t0;
+#endif
         if (ib < 2048) g_times[2 * ib + 1] = (unsigned long long)wall_clock64();
     }
 #endif
@@ -987,7 +1014,9 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     }
     if (search == 2 && keeps) {
         int lv = (int)sched_view(ch.sched, B).level[ib] & 3;
-        if (lv > policy.max_level) lv = policy.max_level;
+        // (chains with a guide keep level 1 only: the sequential start of their curves)
+        const int lv_max = phase_hint ? 1 : policy.max_level;
+        if (lv > lv_max) lv = lv_max;
         policy.level = lv;
         policy.left = lv > 0 ? 8 : 0;
     }
@@ -1021,12 +1050,13 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     }
     group_sync();
     const bool hinted = p.mode == 0 && (phase_hint || ghint_ok_[g] != 0);
+    // (hinted chains: level 1 stands for the sequential start of the curves, see DENSE_REPAIRS_UP)
+    float dense_avg = 0.0f;  // repairs per curve of the first candidate, lately
     if (search == 2 && hinted) {
         policy.max_level = HINTED_MAX_LEVEL;
-        if (policy.level > policy.max_level) {
-            policy.level = policy.max_level;
-            policy.left = policy.level > 0 ? 8 : 0;
-        }
+        if (policy.level > 1) policy.level = 1;
+        policy.left = policy.level > 0 ? DENSE_HOLD : 0;
+        dense_avg = policy.level > 0 ? 2.0f * DENSE_REPAIRS_UP : 0.0f;
     }
 
     // everything one step leaves behind besides the state itself (the chain's first wave writes)
@@ -1115,7 +1145,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     while (s < S) {
         // ---- this wave's candidate: the (w-w0+1)-th proposal from step s on that passes the
         // bounds
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
         const long long _r0 = clock64();
 #endif
         // Which proposals the waves of the chain work on.  A candidate is a node of the tree of
@@ -1212,7 +1242,10 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             build_layer_table(T, test[w], nl, p.vpvs, lane, nlmax);
             if (policy.predicted()) {
                 st = forward_predicted(T, p.wave, p.mode, p.itype, t, P, p.dc, p.dt, newpred[w],
-                                       scratch[w], cnt, policy.stepwise(), pred, ghint,
+                                       scratch[w], cnt,
+                                       hinted ? (policy.level > 0 ? -DENSE_PREFIX(P) : 0)
+                                              : policy.stepwise(),
+                                       pred, ghint,
                                        // (after an acceptance on the path the current curve is
                                        // two moves away: a guide for the windows only)
                                        !hinted ? 0 : ((mybits == 0 || SPEC_HINT_SMALL) && small_moves && fabs(czc) <= hlim[kkc] ? 2 : 1));
@@ -1260,11 +1293,11 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             r_logL[w] = lnew;
             r_lit[w] = cnt.lit;
         }
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
         const long long _b0 = clock64();
 #endif
         group_sync();
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
         if (lane == 0) {
             atomicAdd(&g_prof[9], (unsigned long long)(clock64() - _b0));   // wait for the partner
             atomicAdd(&g_prof[10], (unsigned long long)(_b0 - _r0));        // scan + forward
@@ -1312,14 +1345,33 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             cb |= acc << cl;
             ++cl;
         }
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
         if (writer && lane == 0 && ib < 1024) {
             g_blk[ib * 8 + 7] += 1ull << 40;                       // rounds
             g_blk[ib * 8 + 7] += (unsigned long long)ran << 20;    // forwards run
             g_blk[ib * 8 + 7] += (policy.level == 3) ? ran : 0;    // of which wave-sequential
         }
 #endif
-        if (search == 2) policy.update(ran, trouble2);
+        if (search == 2 && hinted) {
+            // (the first candidate's curve is always needed and never given up)
+            if (r_step[w0] < S && r_st[w0] != MHD_ST_ABORTED)
+                dense_avg += ((float)r_trouble[w0] - dense_avg) * (1.0f / DENSE_WINDOW);
+            if (policy.level == 0) {
+                // (the test build sends every chain there now and then, whatever its curves cost)
+                if (dense_avg > DENSE_REPAIRS_UP || (ABORT_SABOTAGE && (round_no & 15) == 15)) {
+                    policy.level = 1;
+                    policy.left = ABORT_SABOTAGE ? 12 : DENSE_HOLD;
+                }
+            } else {
+                policy.left -= ran;
+                if (policy.left <= 0) {
+                    policy.level = 0;
+                    dense_avg = 0.9f * DENSE_REPAIRS_UP;
+                }
+            }
+        } else if (search == 2) {
+            policy.update(ran, trouble2);
+        }
         if (writer && lane == 0)
             r_stop[w0] = deadline != 0 && (unsigned long long)wall_clock64() >= deadline;
         group_sync();

@@ -131,11 +131,19 @@ __device__ __forceinline__ bool abort_requested()
 #define VERIFY_PAIRS 1
 #endif
 
+// -DMHD_PROFILE: per-stage cycle counts and event counts (they slow the kernels by a quarter:
+// every wave adds to the same few counters); with -DMHD_PROFILE_LIGHT only where and when each
+// chain's launches begin and end (g_times, g_blk[..][5]), which costs nothing measurable
+#if defined(MHD_PROFILE) && !defined(MHD_PROFILE_LIGHT)
+#define MHD_PROFILE_STAGES 1
+#endif
 #ifdef MHD_PROFILE
 __device__ unsigned long long g_prof[64];
 __device__ unsigned long long g_times[4096];
 __device__ unsigned long long g_blk[1024 * 8];
 __device__ unsigned int g_chain[1024 * 32];  // event counts per chain, see CHAIN_EVENT
+#endif
+#ifdef MHD_PROFILE_STAGES
 #define CHAIN_EVENT(i) { const int _pc = g_PS.prof_slot; if ((threadIdx.x & 63) == 0 && _pc >= 0 && _pc < 1024) atomicAdd(&g_chain[_pc * 32 + (i)], 1u); }
 #define PROF_T0 long long _t0 = clock64();
 #define PROF_ADD(i) { long long _t1 = clock64(); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_prof[i], (unsigned long long)(_t1 - _t0)); const int _ps = g_PS.prof_slot; if (_ps >= 0 && _ps < 1024) atomicAdd(&g_blk[_ps * 8 + i], (unsigned long long)(_t1 - _t0)); } _t0 = _t1; }
@@ -182,7 +190,7 @@ __device__ __forceinline__ int predict_coarse(int wave, const double* t, int kbe
     double shift_prev = 0.0;
     int shift_at = -2;    // the period shift_prev belongs to
     int hint_misses = 0;  // rounds in which it bracketed nothing
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
     int prof_first = 0, prof_shaped = 0, prof_shaped_res = 0, prof_lat = 0, prof_lat_res = 0, prof_carry = 0, prof_down = 0;
 #endif
 
@@ -192,7 +200,7 @@ __device__ __forceinline__ int predict_coarse(int wave, const double* t, int kbe
         // the abscissae wbase[q] + j*dc
         int nq = 0, g = 1;
         const bool shaped = use_hint && hint_ok && k0 > 0 && !carry;
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
         prof_first += (k0 == 0 && !carry);
         prof_shaped += shaped;
         prof_carry += carry;
@@ -288,7 +296,7 @@ __device__ __forceinline__ int predict_coarse(int wave, const double* t, int kbe
                 const unsigned long long wm = (1ull << W) - 1ull;
                 const unsigned long long ng = (neg >> bit0) & wm, ps = (pos >> bit0) & wm;
                 const unsigned long long chg = ((ng << 1) & ps) | ((ps << 1) & ng);
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
                 if ((__popcll(chg) != 1 || __popcll(ng | ps) != W) && lane == 0) {
                     atomicAdd(&g_prof[40 + (__popcll(chg) == 0 ? 0 : 1)], 1ull);
                     atomicAdd(&g_prof[42], (unsigned long long)q);
@@ -468,7 +476,7 @@ __device__ __forceinline__ int predict_coarse(int wave, const double* t, int kbe
             ++resolved;
             carry = false;
         }
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
         if (shaped) prof_shaped_res += resolved; else if (k0 > 0) prof_lat_res += resolved;
 #endif
         k0 += resolved;
@@ -484,7 +492,7 @@ __device__ __forceinline__ int predict_coarse(int wave, const double* t, int kbe
         }
     }
     wave_sync();
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
     if (lane == 0) {
         atomicAdd(&g_prof[14], (unsigned long long)rounds);
         atomicAdd(&g_prof[15], 1ull);
@@ -752,14 +760,14 @@ __device__ __forceinline__ int predict_hint(int wave, const double* t, int P, do
             if (it >= 2 && abort_requested()) return -1;
             if (nfail != 0ull) {
                 HINT_WHY(16)
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
                 if (lane == 0) atomicAdd(&g_prof[19], (unsigned long long)it);
 #endif
                 return -1;
             }
             if (todo == 0ull) {
                 HINT_WHY(18)
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
                 if (lane == 0) atomicAdd(&g_prof[17], (unsigned long long)it);
 #endif
                 break;
@@ -1131,6 +1139,10 @@ __device__ VERIFY_INLINE int verify_pass(int wave, const double* t, double tscal
 // Fundamental-mode phase velocities c[0..P-1] (LDS) of the table in g_T, bit-identical to
 // phase_curve_wave(..., mode = 0, ...).  Returns MHD_ST_OK or MHD_ST_NOROOT.
 // stepwise > 0: predict with predict_stepwise(levels = stepwise) instead of predict_coarse.
+// stepwise < 0: the first -stepwise periods by the deferring sequential search (two rounds per
+// period, nothing to repair), the others predicted from where it ends -- for models whose modes
+// lie closer together than the search's step at short periods, where the sequential search hops
+// between branches and every prediction of it costs a repair.
 // hint: see predict_coarse; use_hint 0: none, 1: for predict_coarse, 2: predict_hint first.
 __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int P, double tscale,
                                                   double dc, double* c, EvalCount& cnt,
@@ -1147,18 +1159,43 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
     S.hinted = 0;
     CHAIN_EVENT(0)
     if (stepwise) CHAIN_EVENT(9)
+    const double cc = T.cc, betmx = T.betmx, cm = T.cc;
+    int s1st = 0, kstart = 0, repairs = 0;
+    if (stepwise < 0) {
+        const int kpre = -stepwise < P ? -stepwise : P;
+        auto given_up = [&](int, double) -> bool { return abort_requested(); };
+        const int kdone = sequential_run(wave, t, tscale, 0, kpre, dc, c, s1st, cnt, given_up);
+        PROF_ADD(4)
+        if (kdone < 0) return MHD_ST_NOROOT;
+        if (abort_requested()) return MHD_ST_ABORTED;
+        S.trouble = 0;
+        if (kdone >= P) return MHD_ST_OK;
+        kstart = kdone;
+        nP = predict_coarse(wave, t, kstart, P, tscale, dc, uniform_value(c[kstart - 1]), s1st,
+                            hint, use_hint != 0, cnt);
+        PROF_ADD(0)
+        if (abort_requested()) return MHD_ST_ABORTED;
+        if (nP < 0) {
+            const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kstart, s1st);
+            PROF_ADD(5)
+            return r;
+        }
+        predict_refine(wave, t, kstart, nP, tscale, cnt, false);
+        PROF_ADD(1)
+        stepwise = 0;
+    } else
     if (!stepwise && use_hint == 2) {
         nP = predict_hint(wave, t, P, tscale, dc, hint, cnt);
         S.hinted = nP < 0 ? 2 : 1;
         CHAIN_EVENT(1)
         if (nP < 0) CHAIN_EVENT(2)
         PROF_ADD(0)
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
         if (lane == 0) { atomicAdd(&g_prof[11], 1ull); atomicAdd(&g_prof[12], (unsigned long long)(nP < 0)); }
 #endif
     }
     if (abort_requested()) return MHD_ST_ABORTED;
-    if (nP < 0) {
+    if (nP < 0 && kstart == 0) {
         nP = stepwise ? predict_stepwise(wave, t, 0, P, tscale, dc, 0.0, 0, stepwise, cnt)
                       : predict_coarse(wave, t, 0, P, tscale, dc, 0.0, 0, hint, use_hint != 0, cnt);
         PROF_ADD(0)
@@ -1174,8 +1211,6 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
     }
     S.trouble = 0;
 
-    const double cc = T.cc, betmx = T.betmx, cm = T.cc;
-    int s1st = 0, kstart = 0, repairs = 0;
     for (;;) {
         if (abort_requested()) return MHD_ST_ABORTED;
         // replay periods kstart..kend-1 (c[kstart-1] and s1st are exact); period kplain, if
@@ -1183,7 +1218,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
         const ReplayPass rp = replay_pass(kstart, nP, c, cc, dc, betmx + dc, betmx, s1st);
         const int npts = rp.npts, kfail = rp.kfail, kplain = rp.kplain, kend = rp.kend;
         cnt.rounds += (unsigned)(kend - kstart + 3) >> 2;
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
         if (kplain >= 0) CHAIN_EVENT(7)
 #endif
         PROF_ADD(2)
@@ -1201,7 +1236,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             const int kbad = period_of(first_bad);
             for (int k = klit; k < kbad; ++k) cnt.lit += (int)S.roff[k + 1] - (int)S.roff[k];
             klit = kbad + 1;
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
             if (lane == 0) { atomicAdd(&g_prof[6], 1ull); const int _ps = g_PS.prof_slot; if (_ps >= 0 && _ps < 1024) atomicAdd(&g_blk[_ps * 8 + 6], 1ull); }
 #endif
             S.trouble = repairs + 1;
@@ -1211,7 +1246,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
                 CHAIN_EVENT(10)
                 const int r = phase_curve_wave(T, wave, t, P, tscale, 0, dc, c, cnt, kbad, s1st);
                 PROF_ADD(4)
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
                 if (lane == 0) atomicAdd(&g_prof[7], (unsigned long long)(P - kbad));
 #endif
                 return r;
@@ -1225,7 +1260,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
             PROF_ADD(4)
             if (!ok) return MHD_ST_NOROOT;
             if (abort_requested()) return MHD_ST_ABORTED;
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
             {
                 // where the sequential search ended against the predicted root, and where in the
                 // period the first wrong sign was
@@ -1312,7 +1347,7 @@ __device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int
         }
         if (again) continue;
         for (int k = klit; k < kend; ++k) cnt.lit += (int)S.roff[k + 1] - (int)S.roff[k];
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
         if (lane == 0 && (kend >= nP || kfail >= 0)) atomicAdd(&g_prof[8], 1ull);
 #endif
         if (kfail >= 0) return MHD_ST_NOROOT;
@@ -1372,7 +1407,7 @@ __device__ inline int forward_predicted(const LayerTable& T, int wave, int mode,
     int trouble = 0;
     if (itype != MHD_GROUP) {
         const int st = phase_curve_predicted(wave, t, P, 1.0, dc, vel, cnt, stepwise, hint, use_hint);
-#ifdef MHD_PROFILE
+#ifdef MHD_PROFILE_STAGES
         if (use_hint && st == MHD_ST_OK) {
             // largest shift of a root against the hint, in dc: buckets <1/4, <1/2, <1, <2, ... 
             double mx = 0.0;

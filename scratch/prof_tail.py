@@ -42,3 +42,16 @@ print("the last 25 chains: end us, step the second launch began at, its candidat
 for i in order[-25:]:
     print("  chain %4d end %7.0f from step %3d nw2 %d nw1 %d repairs/fwd %.2f hintfail %.2f notplain/fwd %.2f"%(i,en2[i],steps1[i],nw2[i],nw1[i],rep[i],ev[i,2]/max(ev[i,1],1),ev[i,7]/max(ev[i,0],1)))
 print("all: repairs/fwd p50 %.2f p90 %.2f p99 %.2f; corr(repairs/fwd, end) %.2f"%(*np.percentile(rep,[50,90,99]),np.corrcoef(rep[two],en2[two])[0,1]))
+# where the cycles of the last chain's forwards go, beside the median chain's (whole run, all
+# waves of the chain): predict, refine, replay, verify, repair
+stage = b[:, :5].astype(np.float64)
+fw = np.maximum(ev[:, 0], 1)
+last_i = order[-1]
+names = ["predict", "refine", "replay", "verify", "repair"]
+med = np.median(stage / fw[:, None], axis=0)
+print("cycles per forward by stage: last chain %d: %s = %.0f; median chain: %s = %.0f" % (
+    last_i, " ".join("%s %.0f" % (n, x) for n, x in zip(names, stage[last_i] / fw[last_i])), stage[last_i].sum() / fw[last_i],
+    " ".join("%s %.0f" % (n, x) for n, x in zip(names, med)), med.sum()))
+print("last chain: forwards %d, hint tried %d gave up %d, repairs %d, same-answer %d, same-root-other-lattice %d, predicted anew %d, resynchronised %d, beyond MAX_REPAIRS %d, not plain %d" % (
+    ev[last_i, 0], ev[last_i, 1], ev[last_i, 2], ev[last_i, 4], ev[last_i, 8], ev[last_i, 6], ev[last_i, 5], ev[last_i, 26], ev[last_i, 10], ev[last_i, 7]))
+print("  repairs: search ended above the predicted root %d, below %d, at it %d; wrong sign in the scan %d, in the halvings %d; period >=30: %d, 20-29: %d, 10-19: %d, <10: %d" % tuple(ev[last_i, i] for i in (16, 17, 18, 19, 20, 22, 23, 24, 25)))
