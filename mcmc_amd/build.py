@@ -38,6 +38,10 @@ def _compile(out, extra, force, verbose):
 # (scratch/prof_mh2.py, scratch/prof_short.py).  Not loaded by the package unless MCMC_AMD_LIB
 # names it.
 OUT_PROFILE = os.path.join(HERE, "lib", "libmcmc_amd_prof.so")
+# Its light form (-DMHD_PROFILE -DMHD_PROFILE_LIGHT) records only when each chain's launches
+# begin and end: the stage counters slow the kernels by a quarter and stretch the chains that
+# need repairs, this one runs at full speed (scratch/prof_tail.py).
+OUT_PROFILE_LIGHT = os.path.join(HERE, "lib", "libmcmc_amd_prof_light.so")
 
 
 def build(force=False, verbose=False):
@@ -48,7 +52,11 @@ def build_test_variants(force=False, verbose=False):
     return _compile(OUT_SABOTAGE, ["-DMHD_DEFER_SABOTAGE", "-DMHD_ABORT_SABOTAGE"], force, verbose)
 
 
-def build_profile(force=False, verbose=False):
+def build_profile(force=False, verbose=False, light=False):
+    if light:
+        return _compile(OUT_PROFILE_LIGHT, ["-DMHD_PROFILE", "-DMHD_PROFILE_LIGHT",
+                                            "-Wno-unused-value", "-Wno-unused-variable"],
+                        force, verbose)
     return _compile(OUT_PROFILE, ["-DMHD_PROFILE", "-Wno-unused-value"], force, verbose)
 
 
@@ -57,4 +65,5 @@ if __name__ == "__main__":
     build_test_variants(force="--force" in sys.argv, verbose=True)
     if "--profile" in sys.argv:
         build_profile(force="--force" in sys.argv, verbose=True)
+        build_profile(force="--force" in sys.argv, verbose=True, light=True)
     print(OUT)

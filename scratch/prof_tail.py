@@ -37,6 +37,10 @@ nw2=(b[:,5]&np.uint64(0xffffffff)).astype(int)
 cc=(ctypes.c_uint*32768)(); lib.mhd_debug_chain(cc)
 ev=np.array(list(cc),dtype=np.int64).reshape(1024,32)
 rep=ev[:,4]/np.maximum(ev[:,0],1)
+nw2c = np.where(two & (nw2 < 8), nw2, 0)
+print("second launch: candidates 1/2/4: %d/%d/%d; end us of the chains with 1: med %.0f max %.0f, with 2: med %.0f max %.0f, with 4: med %.0f max %.0f" % (
+    (nw2c == 1).sum(), (nw2c == 2).sum(), (nw2c == 4).sum(),
+    *[f(en2[nw2c == k]) if (nw2c == k).any() else 0 for k in (1, 2, 4) for f in (np.median, np.max)]))
 order=np.argsort(np.where(two,en2,0))
 print("the last 25 chains: end us, step the second launch began at, its candidates, repairs per forward (whole run), hint failures per try")
 for i in order[-25:]:
