@@ -256,6 +256,15 @@ __device__ __forceinline__ void hint_limit_update(float* limit, int kk, double c
 #ifndef DENSE_WINDOW
 #define DENSE_WINDOW 32.0f
 #endif
+// A chain takes the free waves of its workgroup on when it has at least this many steps left
+// (the test build: always)
+#ifndef ADOPT_MIN_STEPS
+#ifdef MHD_ABORT_SABOTAGE
+#define ADOPT_MIN_STEPS 1
+#else
+#define ADOPT_MIN_STEPS 2
+#endif
+#endif
 struct SearchPolicy {
     int level, left;
     int max_level;  // 3, or 0 where the predictor has the chain's current curve to go by: there
@@ -602,6 +611,9 @@ constexpr int SCHED_MIN_CHAINS = 64;    // fewer chains leave the GPU empty howe
 #ifndef SCHED_GAIN
 #define SCHED_GAIN 0.5f
 #endif
+#ifndef SCHED_LATER_FOUR
+#define SCHED_LATER_FOUR 0
+#endif
 // share of a chain's steps that have a forward model, before the chain has shown its own
 #ifndef SCHED_PVALID_PRIOR
 #define SCHED_PVALID_PRIOR 0.85f
@@ -668,19 +680,20 @@ __host__ __device__ inline SchedView sched_view(void* buf, int B)
 #define SCHED_PHASES_N 2
 #endif
 constexpr int SCHED_PHASES = SCHED_PHASES_N;
-// Calls of fewer steps are one launch.  (Measured with calls of 25 ... 60 steps: two launches
-// gain 14-17 % where the chains' durations are spread -- tempered ladders, chains far from the
-// data -- and lose 1-2 % on chains that have settled at the data; below some 24 steps a deadline
-// and a second launch cost more than they even out.)
+// Calls of fewer steps are one launch: chains that share a workgroup hand their waves on when
+// they are done (mh_steps_multi_kernel), which evens a short call out better than a deadline and
+// a second launch do.  (Measured from prior draws, one launch against two: calls of 24 steps
+// 3.32 against 2.89 M steps/s, 32 steps 3.37 against 3.04 M, 40 steps 3.51 against 3.66 M, 60
+// steps 3.53 against 3.70 M.)
 #ifndef SCHED_MIN_STEPS
-#define SCHED_MIN_STEPS 24
+#define SCHED_MIN_STEPS 48
 #endif
 constexpr int SCHED_PHASES_MIN_STEPS = SCHED_MIN_STEPS;
 #ifndef PHASE_DEADLINE_LATER
 #define PHASE_DEADLINE_LATER 1.0f  // later deadlines, in units of the median unfinished chain's
 #endif
 #ifndef PHASE_DEADLINE_FRACTION
-#define PHASE_DEADLINE_FRACTION 0.8f  // first deadline, in units of the median chain's expected time
+#define PHASE_DEADLINE_FRACTION 0.7f  // first deadline, in units of the median chain's expected time
 #endif
 
 // the share of its forwards chain i accepted lately (SPEC_PACC_START while not known)
@@ -773,7 +786,9 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
             int left = 0;
             while (left < B && key[left] > 0.0f) ++left;
             v.n4[5] = left;
-            const int room = 2 * B > slots ? 0 : (slots - 2 * left) / 2;
+            // (SCHED_LATER_FOUR 0: none -- the chains with most work left share their workgroups
+            // with the finished ones and take their waves on at once, see mh_steps_multi_kernel)
+            const int room = (2 * B > slots || !SCHED_LATER_FOUR) ? 0 : (slots - 2 * left) / 2;
             n4 = room < 0 ? 0 : (room < left ? room : left);
             const int cap = sched_cap4(B, phase);
             if (n4 > cap) n4 = cap;
@@ -801,7 +816,11 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
 // step consumes are those of the one-candidate kernel.
 //
 // scheduled (NW = 4): the workgroups take their chains from the launch schedule (see SchedView)
-// and hold one chain with four candidates, two with two each or four with one each.
+// and hold one chain with four candidates, two with two each or four with one each.  Of two
+// chains that share a workgroup the one that is done first (or has nothing to do in this launch)
+// hands its two waves to the other, which runs four candidates from its next round on: the
+// workgroups pair the k-th chain of the order with the k-th from its end, so the chains expected
+// to take longest get that help soonest.
 #ifndef ABORT_MOOT
 #define ABORT_MOOT 1
 #endif
@@ -856,6 +875,18 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
                                            // packs one, two or four into a workgroup of four waves)
     __shared__ long long cbase_[NG][5];    // the chain's counters when the launch starts
     __shared__ unsigned pair_arrivals[2];  // see pair_sync
+    // Two chains that share a workgroup hand their waves on: the waves of the one that is done
+    // first (or that has nothing to do in this launch) run two more candidates of the other.
+    // help_wait_[g]: the waves of slot g are free; help_state_[g]: 0 the chain of slot g runs
+    // with its own two waves, 1 it has taken the other two on, 2 it is done.
+    struct ChainShare {
+        int ib, s, round_no, pacc_n, level, left, max_level, hinted;
+        float pacc, dense_avg;
+        double logL;
+    };
+    __shared__ ChainShare share_[2];
+    __shared__ int help_wait_[2], help_state_[2];
+    __shared__ int r_adopt[NW];
     __shared__ double lo[MAXNP], hi[MAXNP], rg[MAXNP];
     __shared__ double t[MAXP];
     __shared__ double m_[NG][MAXNP];    // current parameters
@@ -886,6 +917,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     int ib = blockIdx.x;
     int g = 0, w0 = 0, nw = NW;  // chain slot in the workgroup, the chain's first wave, its waves
     bool idle = false;           // nothing for this wave in this launch
+    bool pairs_wg = false;       // the workgroup holds two chains with two candidates each
     if (NW == 4 && scheduled) {
         const SchedView sv = sched_view(ch.sched, B);
         const int n4 = sv.n4[0], n1 = sv.n4[1];
@@ -894,11 +926,15 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         int slot = ib;                      // the chain's place in the launch order
         if (ib < n4) {
         } else if (ib < n4 + np) {
+            // (the k-th of them with the k-th from the end: whoever is done first hands its
+            // waves to the other, and the chains that take longest get the most of that)
             g = w >> 1;
             w0 = 2 * g;
             nw = 2;
-            slot = n4 + 2 * (ib - n4) + g;
-            idle = slot >= n4 + pairs;
+            pairs_wg = true;
+            const int k = ib - n4;
+            slot = g == 0 ? n4 + k : n4 + pairs - 1 - k;
+            idle = g == 1 && pairs - 1 - k <= k;
         } else if (ib < n4 + np + n1) {
             g = w;
             w0 = w;
@@ -920,7 +956,8 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         ib = __builtin_amdgcn_readfirstlane(sv.order[ib]);
         idle = sv.progress[ib] >= S;
     }
-    const bool writer = (w == w0);
+    bool writer = (w == w0);
+    const auto wave_of = [&](int q) { return (w0 + q) & (NW - 1); };  // the chain's q-th wave
     // The waves of a chain meet after every round: all waves of the workgroup in its barrier,
     // two of its four by counting arrivals in LDS (pair_sync), one alone not at all.
     unsigned pair_target = 0;
@@ -945,16 +982,21 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         else if (nw == NW) __syncthreads();
         else pair_sync();
     };
-    double* m = m_[g];
-    double* mn = mn_[g];
-    double* wid = wid_[g];
-    double* pred = pred_[g];
-    float* hlim = hlim_[g];
-    double* ghint = ghint_[g];
+    double *m, *mn, *wid, *pred, *ghint;
+    float* hlim;
+    const auto bind_slot = [&]() {
+        m = m_[g];
+        mn = mn_[g];
+        wid = wid_[g];
+        pred = pred_[g];
+        hlim = hlim_[g];
+        ghint = ghint_[g];
+    };
+    bind_slot();
 
     const long long t_begin = wall_clock64();
     const int nlmax = p.n_layers, NP = 2 * nlmax + 1, P = p.n_periods, ND = data_length(p);
-    const int nl = layers_of(p, ib);
+    int nl = layers_of(p, ib);
     LayerTable& T = g_T;
     if (lane == 0) {
         g_PS.prof_slot = ib;
@@ -967,10 +1009,19 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         rg[threadIdx.x] = p.bounds[3 * threadIdx.x + 2];
     }
     for (int k = threadIdx.x; k < P; k += 64 * NW) t[k] = p.periods[k];
-    if (threadIdx.x < 2) pair_arrivals[threadIdx.x] = 0u;
-    __syncthreads();  // the only barrier that chains sharing a workgroup share
-    if (idle) return;
-    if (writer) {
+    if (threadIdx.x < 2) {
+        pair_arrivals[threadIdx.x] = 0u;
+        help_wait_[threadIdx.x] = 0;
+        help_state_[threadIdx.x] = 0;
+    }
+    __syncthreads();  // the only barrier that chains sharing a workgroup share from the start
+    if (idle && !pairs_wg) return;
+    int pass = 0;      // 1: this wave runs candidates of the workgroup's other chain
+    bool run = !idle;  // (a pair of waves without a chain of its own goes straight to helping)
+again:
+    if (run) {
+    const ChainShare sh = share_[g];  // (read by the waves that were taken on only)
+    if (pass == 0 && writer) {
         if (lane < NP) {
             m[lane] = ch.m[(size_t)ib * NP + lane];
             wid[lane] = ch.width[(size_t)ib * NP + lane];
@@ -980,7 +1031,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         for (int k = lane; k < ND; k += 64) pred[k] = ch.pred[(size_t)ib * ND + k];
         if (lane < 5) cbase_[g][lane] = ch.counters[(size_t)ib * 5 + lane];
     }
-    double logL = uniform_value(ch.logL[ib]);
+    double logL = pass ? sh.logL : uniform_value(ch.logL[ib]);
     const double beta = uniform_value(ch.beta ? ch.beta[ib] : 1.0);
     const double* R = (rotate & MHD_ROT_FRAME) ? ch.rot + (size_t)ib * NP * NP : nullptr;
     const ProposalFrame frame = {lo, hi, rg, wid, R, nl, NP, nlmax,
@@ -1034,8 +1085,8 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
     // current curve does for phase velocity, but they are not part of a chain's state: the
     // chain's first wave computes them once per launch (and on every acceptance they are the
     // candidate's).
-    if (writer && lane == 0) ghint_ok_[g] = 0;
-    if (group_kind && p.mode == 0 && search == 2 && writer) {
+    if (pass == 0 && writer && lane == 0) ghint_ok_[g] = 0;
+    if (pass == 0 && group_kind && p.mode == 0 && search == 2 && writer) {
         wave_sync();
         build_layer_table(T, m, nl, p.vpvs, lane, nlmax);
         EvalCount extra = {0, 0, 0};
@@ -1048,8 +1099,9 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         exec += extra.exec;
         wave_sync();
     }
-    group_sync();
-    const bool hinted = p.mode == 0 && (phase_hint || ghint_ok_[g] != 0);
+    // (waves that were taken on meet the chain's own here, see the end of the round loop)
+    if (pass == 0) group_sync(); else __syncthreads();
+    const bool hinted = pass ? sh.hinted != 0 : p.mode == 0 && (phase_hint || ghint_ok_[g] != 0);
     // (hinted chains: level 1 stands for the sequential start of the curves, see DENSE_REPAIRS_UP)
     float dense_avg = 0.0f;  // repairs per curve of the first candidate, lately
     if (search == 2 && hinted) {
@@ -1057,6 +1109,14 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         if (policy.level > 1) policy.level = 1;
         policy.left = policy.level > 0 ? DENSE_HOLD : 0;
         dense_avg = policy.level > 0 ? 2.0f * DENSE_REPAIRS_UP : 0.0f;
+    }
+    if (pass) {
+        pacc = sh.pacc;
+        pacc_n = sh.pacc_n;
+        policy.level = sh.level;
+        policy.left = sh.left;
+        policy.max_level = sh.max_level;
+        dense_avg = sh.dense_avg;
     }
 
     // everything one step leaves behind besides the state itself (the chain's first wave writes)
@@ -1134,6 +1194,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         s = sv.progress[ib];
         deadline = (unsigned long long)(unsigned)sv.n4[2] | ((unsigned long long)(unsigned)sv.n4[3] << 32);
     }
+    if (pass) s = sh.s;
     const int s_begin = s;
 #ifdef MHD_PROFILE
     // where the chain's last launch of the call started: step, candidates
@@ -1141,7 +1202,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         g_blk[ib * 8 + 5] = ((unsigned long long)s << 32) | (unsigned long long)nw;
     if (writer && lane == 0 && ib < 1024 && s == 0) g_times[2 * (1024 + ib)] = (unsigned long long)wall_clock64();
 #endif
-    int round_no = 0;
+    int round_no = pass ? sh.round_no : 0;
     while (s < S) {
         // ---- this wave's candidate: the (w-w0+1)-th proposal from step s on that passes the
         // bounds
@@ -1184,7 +1245,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             nlen[3] = kind == 1 ? 1 : (kind == 2 ? 2 : 3);
             nbits[3] = kind == 0 ? 0 : (kind == 1 ? 1 : (kind == 2 ? 3 : 7));
         }
-        const int wi = w - w0;
+        const int wi = (w - w0) & (NW - 1);
         int mylen = 0, mybits = 0;
 #pragma unroll
         for (int q = 0; q < NW; ++q)
@@ -1236,7 +1297,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         int st = MHD_ST_BOUNDS, trouble = 0;
         double lnew = 0.0;
         EvalCount cnt = {0, 0, 0};
-        if (lane == 0) g_PS.abort = (ABORT_SABOTAGE && w > w0 && round_no % 3 == 1) ? 1 : 0;
+        if (lane == 0) g_PS.abort = (ABORT_SABOTAGE && wi > 0 && round_no % 3 == 1) ? 1 : 0;
         ++round_no;
         if (jc < S) {
             build_layer_table(T, test[w], nl, p.vpvs, lane, nlmax);
@@ -1278,10 +1339,10 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
                     if (q != wi && q < nw && nlen[q] > mylen &&
                         (nbits[q] & ((1 << mylen) - 1)) == 0 && ((nbits[q] >> mylen) & 1) != out &&
                         lane == 0)
-                        g_PS_OF(w0 + q).abort = 1;
+                        g_PS_OF(wave_of(q)).abort = 1;
             }
             if (ABORT_SABOTAGE && lane == 0)
-                for (int c = w + 1; c < w0 + nw; ++c) g_PS_OF(c).abort = 1;
+                for (int q = wi + 1; q < nw; ++q) g_PS_OF(wave_of(q)).abort = 1;
 #ifdef MHD_ABORT_SABOTAGE
             if (st == MHD_ST_ABORTED && lane == 0) atomicAdd(&g_abort_stats[0], 1ull);
 #endif
@@ -1307,7 +1368,8 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         // ---- settle the steps in order (all waves of the chain follow; the first one writes)
         int ran = 0;
         bool trouble2 = false;
-        for (int c = w0; c < w0 + nw; ++c) {
+        for (int q = 0; q < nw; ++q) {
+            const int c = wave_of(q);
             ran += (r_step[c] < S);
             trouble2 |= r_trouble[c] >= (hinted ? HINTED_TROUBLE_MIN : 2);
         }
@@ -1317,7 +1379,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             int c = -1;
 #pragma unroll
             for (int q = 0; q < NW; ++q)
-                if (q < nw && nlen[q] == cl && nbits[q] == cb) c = w0 + q;
+                if (q < nw && nlen[q] == cl && nbits[q] == cb) c = wave_of(q);
             if (c < 0) break;         // nobody ran this node
             const int j = r_step[c];  // <= S
             for (; s < j; ++s) {
@@ -1345,7 +1407,7 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             cb |= acc << cl;
             ++cl;
         }
-#ifdef MHD_PROFILE_STAGES
+#ifdef MHD_PROFILE
         if (writer && lane == 0 && ib < 1024) {
             g_blk[ib * 8 + 7] += 1ull << 40;                       // rounds
             g_blk[ib * 8 + 7] += (unsigned long long)ran << 20;    // forwards run
@@ -1372,10 +1434,42 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
         } else if (search == 2) {
             policy.update(ran, trouble2);
         }
-        if (writer && lane == 0)
-            r_stop[w0] = deadline != 0 && (unsigned long long)wall_clock64() >= deadline;
+        if (writer && lane == 0) {
+            const int stop = deadline != 0 && (unsigned long long)wall_clock64() >= deadline;
+            r_stop[w0] = stop;
+            // the other two waves of the workgroup are free: from the next round on they run
+            // two more candidates of this chain
+            int adopt = 0;
+            if (NW == 4 && pairs_wg && nw == 2 && !stop && S - s >= ADOPT_MIN_STEPS &&
+                __hip_atomic_load(&help_wait_[1 - g], __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                adopt = 1;
+                ChainShare& out = share_[g];
+                out.ib = ib;
+                out.s = s;
+                out.round_no = round_no;
+                out.pacc_n = pacc_n;
+                out.level = policy.level;
+                out.left = policy.left;
+                out.max_level = policy.max_level;
+                out.hinted = hinted;
+                out.pacc = pacc;
+                out.dense_avg = dense_avg;
+                out.logL = logL;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __hip_atomic_store(&help_state_[g], 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            r_adopt[w0] = adopt;
+        }
         group_sync();
         if (r_stop[w0]) break;
+        if (NW == 4 && r_adopt[w0]) {
+            // (set for a chain with two waves only; the waves taken on wait in this barrier,
+            // which is the workgroup's from here on)
+            nw = NW;
+            __syncthreads();
+        }
     }
 
 #ifdef MHD_PROFILE
@@ -1431,6 +1525,38 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
             if (n_evals) atomicAdd(&n_evals[0], lit);
         }
         if (n_evals) atomicAdd(&n_evals[1], exec);
+    }
+    }  // if (run)
+    if (NW == 4 && pairs_wg && pass == 0 && nw == 2) {
+        // This pair of waves is done with its own chain (or had none): it says so, and waits
+        // for the workgroup's other chain to take it on or to end.  (That chain ends, or takes
+        // the waves on, after the round it is in; the limit only keeps a defect from hanging
+        // the GPU.)
+        if (w == w0 && lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&help_state_[g], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&help_wait_[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        int other = 0;
+        for (unsigned spins = 0; spins < (1u << 25); ++spins) {
+            other = __builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                &help_state_[1 - g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (other != 0) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (other == 1) {
+            g = 1 - g;
+            w0 = 2 * g;
+            nw = NW;
+            writer = false;
+            ib = __builtin_amdgcn_readfirstlane(share_[g].ib);
+            nl = layers_of(p, ib);
+            bind_slot();
+            pass = 1;
+            run = true;
+            goto again;
+        }
     }
 }
 

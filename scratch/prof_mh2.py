@@ -3,7 +3,7 @@ predictors, for bench.py's headline run.  python scratch/prof_mh2.py [bench args
 import os, sys, ctypes, json
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import mcmc_amd._lib as L
-L.LIB_PATH=os.path.join(ROOT,'mcmc_amd','lib','libmcmc_amd_prof.so')
+L.LIB_PATH=os.environ.get('MCMC_AMD_LIB') or os.path.join(ROOT,'mcmc_amd','lib','libmcmc_amd_prof.so')
 import torch; torch.cuda.init(); torch.zeros(1,device="cuda"); lib=L.lib()
 sys.argv=['bench.py','--steps','400','--warmup','100','--no-cpu']+sys.argv[1:]
 import runpy, io, contextlib

@@ -3,7 +3,7 @@ import os, sys, ctypes, json
 import numpy as np
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import mcmc_amd._lib as L
-L.LIB_PATH=os.path.join(ROOT,'mcmc_amd','lib','libmcmc_amd_prof.so')
+L.LIB_PATH=os.environ.get('MCMC_AMD_LIB') or os.path.join(ROOT,'mcmc_amd','lib','libmcmc_amd_prof.so')
 import torch; torch.cuda.init(); torch.zeros(1,device="cuda"); lib=L.lib()
 steps = sys.argv[1] if len(sys.argv) > 1 else '20'
 sys.argv=['bench.py','--steps',steps,'--warmup','5','--no-cpu']+sys.argv[2:]

@@ -302,7 +302,7 @@ def test_scheduled_launch_of_more_chains_than_fit_at_once(oracle, candidates):
     if candidates != 2:
         pytest.skip("scheduling applies to the default number of candidates")
     rng = np.random.default_rng(19)
-    nl, P, B, S = 3, 12, 1100, 60
+    nl, P, B, S = 3, 12, 1100, 120
     NP = 2 * nl + 1
     periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
     bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
@@ -327,8 +327,8 @@ def test_scheduled_launch_of_more_chains_than_fit_at_once(oracle, candidates):
             ch.sched = None
         assert int((ch.init_likelihood() != 0).sum()) == 0
         acc = []
-        for a in range(0, S, 30):   # the second call knows the costs and is made of two launches
-            acc.append(ch.steps(idx[a:a + 30], cauchy[a:a + 30], u_acc[a:a + 30])["accepted"])
+        for a in range(0, S, 60):   # the second call knows the costs and is made of two launches
+            acc.append(ch.steps(idx[a:a + 60], cauchy[a:a + 60], u_acc[a:a + 60])["accepted"])
         results.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(),
                         torch.cat(acc), int(ch.n_evals[0])))
     a, b = results

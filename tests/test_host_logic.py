@@ -122,7 +122,7 @@ def test_stepsize_tuning_argument_validation_without_gpu():
     ch = L.Chains(width=8, counters=8)
     assert lib.mhd_stepsize_tuning(ctypes.byref(p), ctypes.byref(ch), 0, None) == 0
     assert lib.mhd_stepsize_tuning(ctypes.byref(p), ctypes.byref(ch), -1, None) == -22
-    assert lib.mhd_sched_min_steps() == 24
+    assert lib.mhd_sched_min_steps() == 48
     assert lib.mhd_static_reset(None) == -22     # mhd_init() has not been called: no device
 
 
