@@ -113,3 +113,50 @@ def test_static_reset_clears_the_scratch_for_whoever_comes_next():
         torch.cuda.synchronize()
         assert torch.equal(ch.m, ref.m) and torch.equal(ch.logL, ref.logL)
         assert torch.equal(ch.counters, ref.counters)
+
+
+def test_static_entry_point_under_graph_capture():
+    """The use the entry point is for: mhd_static_reset, then a call captured into a HIP graph
+    (torch.cuda.graph) and replayed twice on fresh draws.  Every launch of a call is on the
+    caller's stream and nothing is allocated, so the capture holds the whole call -- on the
+    second replay a scheduled one of two launches, made from the costs the first left in the
+    static scratch.  The chains are those of mhd_mh_steps called eagerly on the same draws."""
+    import torch
+    from mcmc_amd import _lib as L
+    from mcmc_amd.engine import DeviceChains
+    rng = np.random.default_rng(123)
+    B, S = 128, 60
+    prob, starts = _problem(rng, B)
+    dev, NP = prob.device, 2 * NL + 1
+    draws = [(torch.tensor(rng.integers(0, NP, (S, B)).astype(np.int32), device=dev),
+              torch.tensor(np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5)), device=dev),
+              torch.tensor(rng.uniform(size=(S, B)), device=dev)) for _ in range(2)]
+    eager = DeviceChains(prob, starts, 0.05)
+    assert int((eager.init_likelihood() != 0).sum()) == 0
+    want = []
+    for idx, cz, ua in draws:
+        out = eager.steps(idx, cz, ua)
+        want.append((eager.m.clone(), eager.logL.clone(), eager.counters.clone(),
+                     out["accepted"].clone()))
+    ch = DeviceChains(prob, starts, 0.05)
+    ch.sched = None
+    assert int((ch.init_likelihood() != 0).sum()) == 0
+    idx_s, cz_s, ua_s = (torch.empty_like(x) for x in draws[0])
+    stream = torch.cuda.Stream(device=dev)
+    stream.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(stream):
+        L.check(L.lib().mhd_static_reset(
+            __import__("ctypes").c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            out = ch.steps(idx_s, cz_s, ua_s, static_scratch=True)
+        for (idx, cz, ua), (m, logL, counters, acc) in zip(draws, want):
+            idx_s.copy_(idx)
+            cz_s.copy_(cz)
+            ua_s.copy_(ua)
+            graph.replay()
+            stream.synchronize()
+            assert torch.equal(ch.m, m) and torch.equal(ch.counters, counters)
+            assert torch.equal(ch.logL, logL) and torch.equal(out["accepted"], acc)
+    torch.cuda.current_stream(dev).wait_stream(stream)
+    assert int(ch.n_evals[0]) == int(eager.n_evals[0])
