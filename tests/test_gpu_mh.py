@@ -337,6 +337,54 @@ def test_scheduled_launch_of_more_chains_than_fit_at_once(oracle, candidates):
     assert a[5] == b[5]
 
 
+def test_scheduled_launches_of_an_odd_number_of_chains(oracle, candidates):
+    """67 chains: the last workgroup of two-candidate chains holds one chain only, whose other two
+    waves have nothing of their own and run two more of its candidates from its second round on;
+    in the calls of 60 steps (two launches) chains that are done hand their waves on as well.
+    Same chains as without the schedule."""
+    import torch
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    if candidates != 2:
+        pytest.skip("scheduling applies to the default number of candidates")
+    rng = np.random.default_rng(23)
+    nl, P, B, S = 4, 16, 67, 150
+    NP = 2 * nl + 1
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
+    prob0 = DeviceProblem(nl, 1.75, periods)
+    starts = np.empty((0, NP))
+    while starts.shape[0] < B:
+        cand = np.array([oracle.sort_layers(x, nl)
+                         for x in rng.uniform(bounds[:, 0], bounds[:, 1], size=(2 * B, NP))])
+        _, st = prob0.forward(torch.tensor(cand, device=prob0.device))
+        starts = np.concatenate([starts, cand[st.cpu().numpy() == 0]])
+    starts = starts[:B]
+    obs = oracle.forward(starts[0], nl, 1.75, periods)[1] + 0.025 * rng.standard_normal(P)
+    prob = DeviceProblem(nl, 1.75, periods, obs, "normal", {"std": 0.025}, bounds)
+    dev = prob.device
+    idx = torch.tensor(rng.integers(0, NP, (S, B)).astype(np.int32), device=dev)
+    cauchy = torch.tensor(np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5)), device=dev)
+    u_acc = torch.tensor(rng.uniform(size=(S, B)), device=dev)
+    results = []
+    for scheduled in (True, False):
+        ch = DeviceChains(prob, starts, 0.05)
+        if not scheduled:
+            ch.sched = None
+        assert int((ch.init_likelihood() != 0).sum()) == 0
+        acc = []
+        for a, b in ((0, 10), (10, 30), (30, 90), (90, 150)):   # 10, 20, 60 and 60 steps
+            out = ch.steps(idx[a:b], cauchy[a:b], u_acc[a:b], hist_every=5)
+            acc.append(torch.cat([out["accepted"].flatten().to(torch.float64),
+                                  out["status"].flatten().to(torch.float64),
+                                  out["hist_logL"].flatten(), out["hist_m"].flatten()]))
+        results.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(),
+                        torch.cat(acc), int(ch.n_evals[0])))
+    a, b = results
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+    assert a[5] == b[5]
+
+
 def test_scheduled_rotated_launches_do_not_change_the_chains(oracle, candidates):
     """The deadline of a scheduled call cuts chains between two steps of rotated-frame proposals
     with covariance accumulation: the second launch must go on exactly there (cov_sum, n_cov,
