@@ -308,7 +308,8 @@ def main():
                 # itself: see profiles/ for the counters of this same command
                 "traffic": None,
                 "kernel": "one call of mhd_mh_steps = " + (
-                    "%d x (schedule_kernel, then mh_steps_multi_kernel<4> and <2> side by side)"
+                    "%d x (schedule_kernel, then mh_steps_multi_kernel<4>: workgroups of four "
+                    "waves holding one, two or four chains)"
                     % (2 if min(args.chunk, K) >= L.lib().mhd_sched_min_steps() else 1)
                     if args.candidates == 2
                     else "mh_steps_multi_kernel<%d>" % args.candidates if args.candidates == 4
