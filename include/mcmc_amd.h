@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MHD_ABI_VERSION 6
+#define MHD_ABI_VERSION 7
 
 #define MHD_OK 0
 #define MHD_EINVAL (-22) /* bad argument (size beyond a compiled limit, NULL pointer) */
@@ -210,6 +210,17 @@ const char *mhd_last_error(void);
  * stream, event or memory.  No counterpart in the reference.
  */
 int mhd_init(int32_t device);
+
+/*
+ * How often a wait between the waves of a workgroup has run into its limit (some
+ * ten seconds) on the current device since the library was loaded: the waves of a
+ * chain's candidates meet after every round by counting arrivals in local memory,
+ * and a limit keeps a defect from hanging the GPU.  It is 0 in a working library;
+ * if it is not, the results of the calls since it was last 0 are not valid.
+ * Synchronous (it copies one number from the device): callers ask where they wait
+ * for the device anyway.  No counterpart in the reference.
+ */
+int mhd_wait_timeouts(uint64_t *count);
 
 /*
  * Resident workgroups per compute unit of the one-candidate MH kernel and of the

@@ -19,13 +19,14 @@ PHASE, GROUP, PHASE_AND_GROUP, PHASE_AND_ELL, ELL = 0, 1, 2, 3, 4
 NORMAL, ASYM_LAPLACE = 0, 1
 ROT_ACCUMULATE, ROT_FRAME, PROPOSE_UNIFORM = 1, 2, 4
 MAX_LAYERS, MAX_PERIODS = 15, 128
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EXPORTS = (
     "mhd_abi_version",
     "mhd_last_error",
     "mhd_init",
     "mhd_debug_occupancy",
+    "mhd_wait_timeouts",
     "mhd_sched_bytes",
     "mhd_sched_min_steps",
     "mhd_secular_batch",
@@ -96,6 +97,7 @@ def lib():
     L.mhd_last_error.argtypes = []
     L.mhd_init.argtypes = [c_int32]
     L.mhd_debug_occupancy.argtypes = [c_void_p, c_void_p]
+    L.mhd_wait_timeouts.argtypes = [c_void_p]
     L.mhd_sched_bytes.argtypes = [c_int32]
     L.mhd_sched_bytes.restype = ctypes.c_size_t
     L.mhd_secular_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
@@ -124,3 +126,13 @@ def lib():
 def check(rc):
     if rc != 0:
         raise MhdError(f"mhd call failed ({rc}): {lib().mhd_last_error().decode()}")
+
+
+def check_waits():
+    """Raises if a wait between the waves of a workgroup has ever timed out on the current device
+    (mhd_wait_timeouts): the results since then are not valid.  Synchronises with the device."""
+    n = ctypes.c_uint64(0)
+    check(lib().mhd_wait_timeouts(ctypes.byref(n)))
+    if n.value:
+        raise MhdError(f"{n.value} wait(s) between the waves of a chain timed out on the device: "
+                       "the chains computed since are not valid")

@@ -858,6 +858,9 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
 // reaches them are run again, so nothing but the time taken may change
 // (tests/test_gpu_deferred_tails.py).  g_abort_stats: curves given up, and how many of them the
 // settlement reached, steps settled by a candidate that follows an acceptance.
+// Waits between the waves of a workgroup that ran into their limit (mhd_wait_timeouts): never, in
+// a working library; a call in which one did has wrong results.
+__device__ unsigned long long g_wait_timeouts;
 #ifdef MHD_ABORT_SABOTAGE
 constexpr bool ABORT_SABOTAGE = true;
 __device__ unsigned long long g_abort_stats[3];
@@ -969,12 +972,15 @@ __global__ __launch_bounds__(64 * NW) MHD_REGS void mh_steps_multi_kernel(
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
         // (both waves are resident, so the other one arrives; the limit -- some ten seconds --
         // only keeps a defect from hanging the GPU: results are then wrong, not late)
+        bool met = false;
         for (unsigned spins = 0; spins < (1u << 27); ++spins) {
             const unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
                 &pair_arrivals[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if ((int)(seen - pair_target) >= 0) break;
+            met = (int)(seen - pair_target) >= 0;
+            if (met) break;
             __builtin_amdgcn_s_sleep(2);
         }
+        if (!met && lane == 0) atomicAdd(&g_wait_timeouts, 1ull);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     auto group_sync = [&]() {
@@ -1544,6 +1550,7 @@ again:
             if (other != 0) break;
             __builtin_amdgcn_s_sleep(8);
         }
+        if (other == 0 && lane == 0) atomicAdd(&g_wait_timeouts, 1ull);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (other == 1) {
             g = 1 - g;
@@ -1652,6 +1659,16 @@ size_t mhd_sched_bytes(int32_t B)
 int mhd_abi_version(void) { return MHD_ABI_VERSION; }
 
 // Resident workgroups per CU of the two main kernels (diagnostic).
+int mhd_wait_timeouts(uint64_t* count)
+{
+    if (!count) return fail(MHD_EINVAL, "count is NULL");
+    unsigned long long n = 0;
+    const hipError_t e = hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wait_timeouts), sizeof(n));
+    if (e != hipSuccess) return hip_fail(e, "mhd_wait_timeouts");
+    *count = (uint64_t)n;
+    return MHD_OK;
+}
+
 int mhd_debug_occupancy(int* mh_blocks, int* fwd_blocks)
 {
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(mh_blocks, mh_steps_kernel, 64, 0);

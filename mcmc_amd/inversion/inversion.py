@@ -351,6 +351,8 @@ class Inversion:
         return int(self.swap_counts[1])
 
     def _sync_host(self):
+        with __import__("torch").cuda.device(self.prob.device):
+            L.check_waits()   # (the copies below wait for the device anyway)
         self._m_host = self.state.m.cpu().numpy()
         self._logL_host = self.state.logL.cpu().numpy()
         self._pred_host = self.state.pred.cpu().numpy()

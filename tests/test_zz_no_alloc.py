@@ -30,6 +30,17 @@ def _problem(rng, B):
     return prob, starts
 
 
+def test_no_wait_between_waves_has_timed_out_in_the_tests_before():
+    """The waves of a chain's candidates meet by counting arrivals in local memory, with a limit
+    that keeps a defect from hanging the GPU; the library counts the waits that ran into it
+    (mhd_wait_timeouts).  None may have, in everything the tests collected before this file ran
+    in this process."""
+    import torch
+    from mcmc_amd import _lib as L
+    torch.zeros(1, device="cuda")
+    L.check_waits()
+
+
 def test_static_scratch_entry_point_matches_mhd_mh_steps():
     import torch
     from mcmc_amd.engine import DeviceChains
@@ -160,3 +171,4 @@ def test_static_entry_point_under_graph_capture():
             assert torch.equal(ch.logL, logL) and torch.equal(out["accepted"], acc)
     torch.cuda.current_stream(dev).wait_stream(stream)
     assert int(ch.n_evals[0]) == int(eager.n_evals[0])
+    L.check_waits()
