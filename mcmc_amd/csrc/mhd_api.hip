@@ -89,11 +89,17 @@ __global__ __launch_bounds__(64) MHD_REGS void secular_kernel(mhd_problem_t p, c
     if (q >= N) return;
     const int lane = threadIdx.x;
     const int NP = 2 * p.n_layers + 1;
-    const int ib = chain[q];
+    const int ib = chain[q], ip = period[q];
+    // (the indices come from device memory the host has not seen: a query that points outside
+    // the batch or the periods answers NaN)
+    if (ib < 0 || ib >= B || ip < 0 || ip >= p.n_periods) {
+        if (lane == 0) delta[q] = __builtin_nan("");
+        return;
+    }
     if (lane < NP) m[lane] = params[(size_t)ib * NP + lane];
     __syncthreads();
     build_layer_table(T, m, layers_of(p, ib), p.vpvs, lane, p.n_layers);
-    const double omega = TWOPI / p.periods[period[q]];
+    const double omega = TWOPI / p.periods[ip];
     const double d = secular(T, p.wave, omega, c[q]);
     if (lane == 0) delta[q] = d;
 }

@@ -100,7 +100,12 @@ __device__ __forceinline__ double uniform_value(double x)
 // ---------------------------------------------------------------------------
 // Secular functions.  Only the sign of the result steers the search.
 // ---------------------------------------------------------------------------
-#pragma clang fp contract(fast)
+// Every multiply-add of the period equations is written out (fma_) and the compiler contracts
+// nothing by itself.  The equations are inlined in several places -- one abscissa per lane, two
+// abscissae per lane, the ellipticity -- and a search decides by the SIGN of a value that can be
+// all rounding next to a root: only if every copy rounds alike do the searches, the candidates
+// and the launches of a chain agree on such a sign whichever copy they went through.
+#pragma clang fp contract(off)
 
 // One wave type (P or S) in one layer.  Input: k, xk = omega/v, dpth.
 // Output: cs (cos or scaled cosh), over_r (sin/r or scaled sinh/r), times_r
@@ -139,6 +144,104 @@ __device__ __forceinline__ void osc_or_evan(double k, double xk, double dpth, do
     }
 }
 
+// a * b + c of the period equations' algebra: fused.  (MHD_ALGEBRA_UNFUSED: two roundings, as
+// the reference's arithmetic has them.  Over 163 840 random models the same 8 curves differ
+// from the CPU restatement's either way -- the disagreements come from lattice points next to
+// roots of ill-conditioned equations, not from the fusing -- and the steps are 5 % slower.)
+#ifdef MHD_ALGEBRA_UNFUSED
+__device__ __forceinline__ double mad_(double a, double b, double c) { return a * b + c; }
+#else
+__device__ __forceinline__ double mad_(double a, double b, double c) { return fma_(a, b, c); }
+#endif
+
+// The compound vector of the half-space (the start of the Dunkin recursion).
+__device__ __forceinline__ void compound_halfspace(double k, double k2, double xka, double xkb,
+                                                   double gammk, double rho1, double& e0,
+                                                   double& e1, double& e2, double& e3, double& e4)
+{
+    const double ra = sqrt((k + xka) * fabs(k - xka));
+    const double rb = sqrt((k + xkb) * fabs(k - xkb));
+    const double gam = gammk * k2;
+    const double gamm1 = gam - 1.0;
+    const double rarb = ra * rb;
+    const double gkrr = gammk * rarb;
+    e0 = (rho1 * rho1) * mad_(-gam, gkrr, gamm1 * gamm1);
+    e1 = -rho1 * ra;
+    e2 = rho1 * (gamm1 - gkrr);
+    e3 = rho1 * rb;
+    e4 = mad_(-ra, rb, k2);
+}
+
+// One layer of the Dunkin recursion: e <- e * ca(layer), then rescaled by an exact power of two
+// (sign-preserving, no rounding) whose exponent is added to sexp.  (cosp, w, x, ep) and
+// (cosq, y, z, eq) are the outputs of osc_or_evan for the P and the S wave of the layer.
+__device__ __forceinline__ void compound_layer(double k2, double gammk, double rho1, double irho,
+                                               double cosp, double w, double x, double ep,
+                                               double cosq, double y, double z, double eq,
+                                               double& e0, double& e1, double& e2, double& e3,
+                                               double& e4, int& sexp)
+{
+    // exp(-(pex + sex)); the reference sets it to 0 from an exponent of 60 on, where it is
+    // below 1e-26 of the cosine product it is subtracted from: the same number in double
+    const double a0 = ep * eq;
+    const double gam = gammk * k2;
+    const double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w,
+                 cqx = cosq * x, xy = x * y, xz = x * z, wy = w * y, wz = w * z;
+    const double gamm1 = gam - 1.0;
+    const double twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1,
+                 gm1sq = gamm1 * gamm1, rho2 = rho1 * rho1, a0pq = a0 - cpcq, t = -2.0 * k2,
+                 k2wy = k2 * wy;
+    // ca00 = cpcq - 2 gmgm1 a0pq - gmgmk xz - k2 gm1sq wy
+    double ca00 = mad_(-2.0 * gmgm1, a0pq, cpcq);
+    ca00 = mad_(-gmgmk, xz, ca00);
+    ca00 = mad_(-gm1sq, k2wy, ca00);
+    const double ca01 = mad_(k2, cpy, -cqx) * irho;
+    // ca02 = -(twgm1 a0pq + gammk xz + k2 gamm1 wy) / rho
+    double s02 = twgm1 * a0pq;
+    s02 = mad_(gammk, xz, s02);
+    s02 = mad_(gamm1, k2wy, s02);
+    const double ca02 = -s02 * irho;
+    const double ca03 = mad_(-k2, cqw, cpz) * irho;
+    // ca04 = -(2 k2 a0pq + xz + k2 k2 wy) / rho^2
+    double s04 = mad_(2.0 * k2, a0pq, xz);
+    s04 = mad_(k2, k2wy, s04);
+    const double ca04 = -s04 * (irho * irho);
+    const double ca10 = mad_(gmgmk, cpz, -(gm1sq * cqw)) * rho1;
+    const double ca11 = cpcq;
+    const double ca12 = mad_(gammk, cpz, -(gamm1 * cqw));
+    const double ca13 = -wz;
+    const double ca30 = mad_(gm1sq, cpy, -(gmgmk * cqx)) * rho1;
+    const double ca31 = -xy;
+    const double ca32 = mad_(gamm1, cpy, -(gammk * cqx));
+    // ca40 = -(2 gmgmk gm1sq a0pq + gmgmk^2 xz + gm1sq^2 wy) rho^2
+    double s40 = (2.0 * gmgmk * gm1sq) * a0pq;
+    s40 = mad_(gmgmk * gmgmk, xz, s40);
+    s40 = mad_(gm1sq * gm1sq, wy, s40);
+    const double ca40 = -s40 * rho2;
+    // ca42 = -(gammk gamm1 twgm1 a0pq + gam gammk^2 xz + gamm1 gm1sq wy) rho
+    double s42 = (gammk * gamm1 * twgm1) * a0pq;
+    s42 = mad_(gmgmk * gammk, xz, s42);
+    s42 = mad_(gamm1 * gm1sq, wy, s42);
+    const double ca42 = -s42 * rho1;
+    const double ca20 = t * ca42, ca21 = t * ca32, ca22 = mad_(2.0, cpcq - ca00, a0),
+                 ca23 = t * ca12, ca24 = t * ca02;
+    // ee_i = sum_j e_j ca_ji with ca14=ca03, ca33=ca11, ca34=ca01, ca41=ca30,
+    // ca43=ca10, ca44=ca00
+    const double n0 = mad_(e4, ca40, mad_(e3, ca30, mad_(e2, ca20, mad_(e1, ca10, e0 * ca00))));
+    const double n1 = mad_(e4, ca30, mad_(e3, ca31, mad_(e2, ca21, mad_(e1, ca11, e0 * ca01))));
+    const double n2 = mad_(e4, ca42, mad_(e3, ca32, mad_(e2, ca22, mad_(e1, ca12, e0 * ca02))));
+    const double n3 = mad_(e4, ca10, mad_(e3, ca11, mad_(e2, ca23, mad_(e1, ca13, e0 * ca03))));
+    const double n4 = mad_(e4, ca00, mad_(e3, ca01, mad_(e2, ca24, mad_(e1, ca03, e0 * ca04))));
+    const double t1 = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
+    const int ex = (t1 < 1.0e-40) ? 0 : __builtin_amdgcn_frexp_exp(t1);
+    sexp += ex;
+    e0 = ldexp(n0, -ex);
+    e1 = ldexp(n1, -ex);
+    e2 = ldexp(n2, -ex);
+    e3 = ldexp(n3, -ex);
+    e4 = ldexp(n4, -ex);
+}
+
 // Rayleigh period equation (Dunkin compound matrix).  Returns the first
 // component of the propagated, rescaled vector; *scale_exp receives the sum of
 // the binary exponents taken out, so that value * 2^(*scale_exp) is the
@@ -151,79 +254,26 @@ __device__ __forceinline__ double rayleigh_compound(const LayerTable& T, double 
     const int L = T.L;
     const double k = omega / c;
     const double k2 = k * k;
-    int h = L - 1;
-    double xka = omega * T.inv_a[h];
-    double xkb = omega * T.inv_b[h];
-    double ra = sqrt((k + xka) * fabs(k - xka));
-    double rb = sqrt((k + xkb) * fabs(k - xkb));
-    double gammk = T.twob2[h] * inv_om2;
-    double gam = gammk * k2;
-    double gamm1 = gam - 1.0;
-    double rho1 = T.rho[h];
-    double e0 = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
-    double e1 = -rho1 * ra;
-    double e2 = rho1 * (gamm1 - gammk * ra * rb);
-    double e3 = rho1 * rb;
-    double e4 = k2 - ra * rb;
+    double e0, e1, e2, e3, e4;
+    {
+        const int h = L - 1;
+        compound_halfspace(k, k2, omega * T.inv_a[h], omega * T.inv_b[h], T.twob2[h] * inv_om2,
+                           T.rho[h], e0, e1, e2, e3, e4);
+    }
     int sexp = 0;
 
 #pragma nounroll
     for (int m = L - 2; m >= 0; --m) {
-        xka = omega * T.inv_a[m];
-        xkb = omega * T.inv_b[m];
-        gammk = T.twob2[m] * inv_om2;
-        gam = gammk * k2;
+        const double xka = omega * T.inv_a[m];
+        const double xkb = omega * T.inv_b[m];
         const double dpth = T.d[m];
-        rho1 = T.rho[m];
-        const double irho = T.inv_rho[m];
         double cosp, w, x, ep, pex, cosq, y, z, eq, sex;
         osc_or_evan(k, xka, dpth, cosp, w, x, ep, pex);
         osc_or_evan(k, xkb, dpth, cosq, y, z, eq, sex);
-        // exp(-(pex + sex)); the reference sets it to 0 from an exponent of 60 on, where it is
-        // below 1e-26 of the cosine product it is subtracted from: the same number in double
         (void)pex;
         (void)sex;
-        const double a0 = ep * eq;
-        const double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w,
-                     cqx = cosq * x, xy = x * y, xz = x * z, wy = w * y, wz = w * z;
-        gamm1 = gam - 1.0;
-        const double twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1,
-                     gm1sq = gamm1 * gamm1, rho2 = rho1 * rho1, a0pq = a0 - cpcq,
-                     t = -2.0 * k2;
-        const double ca00 = cpcq - 2.0 * gmgm1 * a0pq - gmgmk * xz - k2 * gm1sq * wy;
-        const double ca01 = (k2 * cpy - cqx) * irho;
-        const double ca02 = -(twgm1 * a0pq + gammk * xz + k2 * gamm1 * wy) * irho;
-        const double ca03 = (cpz - k2 * cqw) * irho;
-        const double ca04 = -(2.0 * k2 * a0pq + xz + k2 * k2 * wy) * (irho * irho);
-        const double ca10 = (gmgmk * cpz - gm1sq * cqw) * rho1;
-        const double ca11 = cpcq;
-        const double ca12 = gammk * cpz - gamm1 * cqw;
-        const double ca13 = -wz;
-        const double ca30 = (gm1sq * cpy - gmgmk * cqx) * rho1;
-        const double ca31 = -xy;
-        const double ca32 = gamm1 * cpy - gammk * cqx;
-        const double ca40 =
-            -(2.0 * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * xz + gm1sq * gm1sq * wy) * rho2;
-        const double ca42 =
-            -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * xz + gamm1 * gm1sq * wy) * rho1;
-        const double ca20 = t * ca42, ca21 = t * ca32, ca22 = a0 + 2.0 * (cpcq - ca00),
-                     ca23 = t * ca12, ca24 = t * ca02;
-        // ee_i = sum_j e_j ca_ji with ca14=ca03, ca33=ca11, ca34=ca01, ca41=ca30,
-        // ca43=ca10, ca44=ca00
-        const double n0 = e0 * ca00 + e1 * ca10 + e2 * ca20 + e3 * ca30 + e4 * ca40;
-        const double n1 = e0 * ca01 + e1 * ca11 + e2 * ca21 + e3 * ca31 + e4 * ca30;
-        const double n2 = e0 * ca02 + e1 * ca12 + e2 * ca22 + e3 * ca32 + e4 * ca42;
-        const double n3 = e0 * ca03 + e1 * ca13 + e2 * ca23 + e3 * ca11 + e4 * ca10;
-        const double n4 = e0 * ca04 + e1 * ca03 + e2 * ca24 + e3 * ca01 + e4 * ca00;
-        // rescale by an exact power of two (sign-preserving, no rounding)
-        const double t1 = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
-        const int ex = (t1 < 1.0e-40) ? 0 : __builtin_amdgcn_frexp_exp(t1);
-        sexp += ex;
-        e0 = ldexp(n0, -ex);
-        e1 = ldexp(n1, -ex);
-        e2 = ldexp(n2, -ex);
-        e3 = ldexp(n3, -ex);
-        e4 = ldexp(n4, -ex);
+        compound_layer(k2, T.twob2[m] * inv_om2, T.rho[m], T.inv_rho[m], cosp, w, x, ep, cosq, y,
+                       z, eq, e0, e1, e2, e3, e4, sexp);
     }
     if (scale_exp) *scale_exp = sexp;
     if (rest) {
@@ -259,8 +309,8 @@ __device__ __forceinline__ double secular_love(const LayerTable& T, double omega
         const double dpth = T.d[m];
         double cosq, y, z, eq, sex;
         osc_or_evan(k, xkb, dpth, cosq, y, z, eq, sex);
-        const double e10 = e1 * cosq + e2 * xmu * z;
-        const double e20 = e1 * y / xmu + e2 * cosq;
+        const double e10 = mad_(e2 * xmu, z, e1 * cosq);
+        const double e20 = mad_(e2, cosq, e1 * y / xmu);
         const double xnor = fmax(fabs(e10), fabs(e20));
         const int ex = (xnor < 1.0e-40) ? 0 : __builtin_amdgcn_frexp_exp(xnor);
         sexp += ex;
@@ -385,17 +435,8 @@ __device__ __forceinline__ void secular_rayleigh2(const LayerTable& T, const dou
             inv_om2[u] = 1.0 / (omega[u] * omega[u]);
             k[u] = omega[u] / c[u];
             k2[u] = k[u] * k[u];
-            const double xka = omega[u] * ia, xkb = omega[u] * ib;
-            const double ra = sqrt((k[u] + xka) * fabs(k[u] - xka));
-            const double rb = sqrt((k[u] + xkb) * fabs(k[u] - xkb));
-            const double gammk = tb2 * inv_om2[u];
-            const double gam = gammk * k2[u];
-            const double gamm1 = gam - 1.0;
-            e0[u] = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
-            e1[u] = -rho1 * ra;
-            e2[u] = rho1 * (gamm1 - gammk * ra * rb);
-            e3[u] = rho1 * rb;
-            e4[u] = k2[u] - ra * rb;
+            compound_halfspace(k[u], k2[u], omega[u] * ia, omega[u] * ib, tb2 * inv_om2[u], rho1,
+                               e0[u], e1[u], e2[u], e3[u], e4[u]);
             sexp[u] = 0;
         }
     }
@@ -413,51 +454,10 @@ __device__ __forceinline__ void secular_rayleigh2(const LayerTable& T, const dou
         osc_or_evan2(k, xka, dpth, cosp, w, x, ep, pex);
         osc_or_evan2(k, xkb, dpth, cosq, y, z, eq, sex);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const double gammk = tb2 * inv_om2[u];
-            const double gam = gammk * k2[u];
-            const double a0 = ep[u] * eq[u];  // (see rayleigh_compound)
-            const double cpcq = cosp[u] * cosq[u], cpy = cosp[u] * y[u], cpz = cosp[u] * z[u],
-                         cqw = cosq[u] * w[u], cqx = cosq[u] * x[u], xy = x[u] * y[u],
-                         xz = x[u] * z[u], wy = w[u] * y[u], wz = w[u] * z[u];
-            const double gamm1 = gam - 1.0;
-            const double twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1,
-                         gm1sq = gamm1 * gamm1, rho2 = rho1 * rho1, a0pq = a0 - cpcq,
-                         t = -2.0 * k2[u];
-            const double ca00 = cpcq - 2.0 * gmgm1 * a0pq - gmgmk * xz - k2[u] * gm1sq * wy;
-            const double ca01 = (k2[u] * cpy - cqx) * irho;
-            const double ca02 = -(twgm1 * a0pq + gammk * xz + k2[u] * gamm1 * wy) * irho;
-            const double ca03 = (cpz - k2[u] * cqw) * irho;
-            const double ca04 = -(2.0 * k2[u] * a0pq + xz + k2[u] * k2[u] * wy) * (irho * irho);
-            const double ca10 = (gmgmk * cpz - gm1sq * cqw) * rho1;
-            const double ca11 = cpcq;
-            const double ca12 = gammk * cpz - gamm1 * cqw;
-            const double ca13 = -wz;
-            const double ca30 = (gm1sq * cpy - gmgmk * cqx) * rho1;
-            const double ca31 = -xy;
-            const double ca32 = gamm1 * cpy - gammk * cqx;
-            const double ca40 =
-                -(2.0 * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * xz + gm1sq * gm1sq * wy) * rho2;
-            const double ca42 =
-                -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * xz + gamm1 * gm1sq * wy) *
-                rho1;
-            const double ca20 = t * ca42, ca21 = t * ca32, ca22 = a0 + 2.0 * (cpcq - ca00),
-                         ca23 = t * ca12, ca24 = t * ca02;
-            const double n0 = e0[u] * ca00 + e1[u] * ca10 + e2[u] * ca20 + e3[u] * ca30 + e4[u] * ca40;
-            const double n1 = e0[u] * ca01 + e1[u] * ca11 + e2[u] * ca21 + e3[u] * ca31 + e4[u] * ca30;
-            const double n2 = e0[u] * ca02 + e1[u] * ca12 + e2[u] * ca22 + e3[u] * ca32 + e4[u] * ca42;
-            const double n3 = e0[u] * ca03 + e1[u] * ca13 + e2[u] * ca23 + e3[u] * ca11 + e4[u] * ca10;
-            const double n4 = e0[u] * ca04 + e1[u] * ca03 + e2[u] * ca24 + e3[u] * ca01 + e4[u] * ca00;
-            const double t1 =
-                fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
-            const int ex = (t1 < 1.0e-40) ? 0 : __builtin_amdgcn_frexp_exp(t1);
-            sexp[u] += ex;
-            e0[u] = ldexp(n0, -ex);
-            e1[u] = ldexp(n1, -ex);
-            e2[u] = ldexp(n2, -ex);
-            e3[u] = ldexp(n3, -ex);
-            e4[u] = ldexp(n4, -ex);
-        }
+        for (int u = 0; u < 2; ++u)
+            compound_layer(k2[u], tb2 * inv_om2[u], rho1, irho, cosp[u], w[u], x[u], ep[u],
+                           cosq[u], y[u], z[u], eq[u], e0[u], e1[u], e2[u], e3[u], e4[u],
+                           sexp[u]);
     }
     val[0] = e0[0];
     val[1] = e0[1];

@@ -13,8 +13,15 @@
 //   rsqrt_pos(x)          1/sqrt(x), x > 0 normal: hardware seed (device) or a
 //                         single-precision one (host) refined by one step of third
 //                         order; < 1 ulp.
+//
+// Every multiply-add is written out (fma_) and the compiler contracts nothing by itself: the
+// routines are inlined into several evaluations of the period equation, which must round alike
+// wherever they stand -- a search decides by the sign of a value that can be all rounding.
 #pragma once
 #include <cmath>
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
 
 #if defined(__HIPCC__)
 #define MHD_HD __host__ __device__ __forceinline__
@@ -82,7 +89,7 @@ MHD_HD void sincos_pio2(double x, double& s, double& c)
     pc = fma_k<SK>(z, pc, C1);
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
-    const double cr = w + (((1.0 - w) - hz) + z * z * pc);
+    const double cr = w + fma_(z * z, pc, (1.0 - w) - hz);
     // quadrant
     const double ss = (q & 1) ? cr : sr;
     const double cs = (q & 1) ? sr : cr;

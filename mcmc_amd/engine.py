@@ -143,6 +143,10 @@ class DeviceProblem:
     def secular(self, params, chain, period, c):
         params = params.contiguous()
         N = chain.numel()
+        assert chain.dtype == torch.int32 and period.dtype == torch.int32, \
+            "chain and period are int32 indices into the batch and the periods"
+        assert c.dtype == torch.float64 and period.numel() == N and c.numel() == N
+        chain, period, c = chain.contiguous(), period.contiguous(), c.contiguous()
         delta = torch.empty(N, dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
             L.check(L.lib().mhd_secular_batch(self.cref(), _ptr(params), params.shape[0],

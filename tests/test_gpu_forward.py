@@ -86,6 +86,62 @@ def test_forward_low_velocity_zones(torch_cuda, oracle, search):
     assert jumps.sum() > B // 8, int(jumps.sum())
 
 
+def test_model_with_a_halving_abscissa_next_to_a_root(torch_cuda, oracle):
+    """A 6-layer model (a 0.15 km/s layer under a 1.56 km/s lid) whose longest period has a
+    halving abscissa 5e-9 relative from a root: the period equation's value there, 5e-11 of its
+    value one lattice step away, is rounding alone.  The two searches reach that abscissa through
+    different evaluations of the equation (one abscissa per lane, two per lane); they must agree
+    with each other bit for bit, and here they agree with the oracle as well."""
+    torch = torch_cuda
+    from mcmc_amd import engine as E
+    from mcmc_amd.engine import DeviceProblem
+    m = np.array([float.fromhex(x) for x in (
+        "0x1.5f04cea1fb866p-10", "0x1.32659f56c2269p-5", "0x1.0d676cad9591cp-4",
+        "0x1.19a16ea03edc6p-3", "0x1.1a5a21d769b5ep-3", "0x1.8f46d93dca59bp+0",
+        "0x1.3550d255a5d1ep-3", "0x1.b4fffc618613fp-1", "0x1.9a5ef93e7824bp+0",
+        "0x1.c4c295cab7da6p+0", "0x1.a4f7eeefa6ee7p-1")])
+    periods = np.flip(1 / np.logspace(0.3, 1.3, 40)).copy()
+    prob = DeviceProblem(5, 1.75, periods)
+    ost, ovel, _ = oracle.forward(m, 5, 1.75, periods)
+    assert ost == 0
+    got = {}
+    try:
+        for search in (1, 2):
+            E.set_default_tuning(search=search)
+            vel, st = prob.forward(torch.tensor(m[None], device=prob.device))
+            assert st.tolist() == [0]
+            got[search] = vel[0].cpu().numpy()
+    finally:
+        E.set_default_tuning(search=0)
+    np.testing.assert_array_equal(got[1], got[2])
+    np.testing.assert_array_equal(got[2], ovel)
+    # the sign at the abscissa between the two answers one lattice step apart
+    c = 0.5 * (0.19655727085962943 + 0.19655696568384817)
+    i32 = dict(dtype=torch.int32, device=prob.device)
+    d = prob.secular(torch.tensor(m[None], device=prob.device), torch.zeros(1, **i32),
+                     torch.full((1,), 39, **i32),
+                     torch.tensor([c], dtype=torch.float64, device=prob.device)).item()
+    od = oracle.secular(*oracle.layer_table(m, 5, 1.75), periods[39], c)
+    assert d > 0 and od > 0 and d < 1e-10
+
+
+def test_secular_query_outside_the_batch_answers_nan(torch_cuda):
+    """mhd_secular_batch reads its chain and period indices on the device: one that points
+    outside the batch or the periods gives NaN for that query, the others are answered."""
+    torch = torch_cuda
+    from mcmc_amd.engine import DeviceProblem
+    rng = np.random.default_rng(3)
+    periods = np.flip(1 / np.logspace(0.3, 1.3, 20)).copy()
+    prob = DeviceProblem(3, 1.75, periods)
+    dev = prob.device
+    params = torch.tensor(prior_draws(rng, 4, 3), device=dev)
+    chain = torch.tensor([0, 4, -1, 3, 2], dtype=torch.int32, device=dev)
+    per = torch.tensor([0, 1, 1, 20, 19], dtype=torch.int32, device=dev)
+    c = torch.full((5,), 0.5, dtype=torch.float64, device=dev)
+    d = prob.secular(params, chain, per, c).cpu().numpy()
+    assert np.isfinite(d[[0, 4]]).all() and np.isnan(d[[1, 2, 3]]).all()
+
+
 def test_forward_golden_curves(torch_cuda):
     """The disba curves embedded in the reference, straight through the HIP path."""
     torch = torch_cuda

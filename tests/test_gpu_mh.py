@@ -522,3 +522,74 @@ def test_rotation_trace(oracle):
         assert int(ch.counters[0, 0]) == rec["n_acc"]
     np.testing.assert_allclose(ch.cov_sum[0].cpu().numpy(), g["final_cov_sum"], rtol=1e-9,
                                atol=1e-18)
+
+
+@pytest.mark.parametrize("search", [2, 1])
+def test_every_recorded_curve_is_the_forward_of_its_parameters(candidates, search):
+    """The curves a chain keeps after each step are bit for bit those of mhd_forward_batch on
+    the parameters it keeps, whichever search and however many candidates made them: 1024 chains
+    of 6 layers x 40 periods over calls of 48 and 60 steps.  Step 59 of the second call takes
+    chain 956 to a model whose last period has a halving abscissa 5e-9 (relative) from a root of
+    the period equation, where the value is rounding alone: the one- and the two-abscissa
+    evaluations of the equation have to round alike for the paths to agree on its sign."""
+    import torch
+    from mcmc_amd import engine as E
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    rng = np.random.default_rng(9123)
+    # (the draws are taken in the order of scratch/soak_sched.py, whose configuration 123 this is)
+    nl = int(rng.integers(2, 8))
+    P = int(rng.choice([8, 16, 24, 40]))
+    B = int(rng.choice([64, 65, 67, 96, 129, 200, 255, 256, 383, 512, 700, 1024, 1100]))
+    itype = str(rng.choice(["phase", "phase", "group", "phase+ellipticity"]))
+    rotate = int(rng.choice([0, 0, 3]))
+    calls = [int(x) for x in rng.choice([3, 7, 12, 20, 30, 47, 48, 60, 90, 130],
+                                        size=int(rng.integers(3, 6)))]
+    assert (nl, P, B, itype, rotate, calls) == (5, 40, 1024, "phase", 0, [48, 60, 12, 48, 3])
+    NP = 2 * nl + 1
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
+    prob0 = DeviceProblem(nl, 1.75, periods)
+    starts = np.empty((0, NP))
+    while starts.shape[0] < B:
+        cand = rng.uniform(bounds[:, 0], bounds[:, 1], size=(2 * B, NP))
+        order = np.argsort(cand[:, :nl], axis=1, kind="stable")
+        cand[:, :nl] = np.take_along_axis(cand[:, :nl], order, axis=1)
+        cand[:, nl:2 * nl] = np.take_along_axis(cand[:, nl:2 * nl], order, axis=1)
+        _, st = prob0.forward(torch.tensor(cand, device=prob0.device))
+        starts = np.concatenate([starts, cand[st.cpu().numpy() == 0]])
+    starts = starts[:B]
+    true = prob0.forward(torch.tensor(starts[:1], device=prob0.device))[0][0].cpu().numpy()
+    obs = true + 0.03 * rng.standard_normal(P)
+    prob = DeviceProblem(nl, 1.75, periods, obs, "normal", {"std": 0.03}, bounds)
+    dev = prob.device
+    rng.uniform()
+    S = sum(calls)
+    idx = torch.tensor(rng.integers(0, NP, (S, B)).astype(np.int32), device=dev)
+    cz = torch.tensor(np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5)), device=dev)
+    ua = torch.tensor(rng.uniform(size=(S, B)), device=dev)
+    calls = calls[:2]
+    reached = False
+    E.set_default_tuning(search=search)
+    try:
+        for scheduled in (True, False):
+            ch = DeviceChains(prob, starts, 0.05)
+            if not scheduled:
+                ch.sched = None
+            assert int(ch.init_likelihood().abs().sum()) == 0
+            a = 0
+            for n in calls:
+                o = ch.steps(idx[a:a + n], cz[a:a + n], ua[a:a + n], hist_every=1,
+                             want_pred_hist=True)
+                a += n
+                E.set_default_tuning(search=3 - search, candidates=0)   # the other search
+                pr, st = prob.forward(o["hist_m"].reshape(n * B, NP))
+                E.set_default_tuning(search=search, candidates=candidates)
+                assert int(st.abs().sum()) == 0
+                bad = (pr != o["hist_pred"].reshape(n * B, P)).any(1).reshape(n, B).nonzero()
+                assert bad.shape[0] == 0, f"(step, chain) {bad[:5].tolist()}"
+                if n == 60:
+                    reached = reached or o["hist_m"][59, 956, 4].item() == float.fromhex(
+                        "0x1.1a5a21d769b5ep-3")
+    finally:
+        E.set_default_tuning(search=0)
+    assert reached, "the chains no longer pass through the model this test is about"
