@@ -231,14 +231,32 @@ int mhd_debug_occupancy(int *mh_blocks, int *fwd_blocks);
 
 /*
  * Secular (period-equation) function values, for diagnostics and parity gates:
- * delta[i] = Delta(c[i]) of chain chain[i] at period index period[i].
- * Replaces nothing the reference calls directly; it is disba's dltar4 / dltar1
+ * delta[i] = Delta(c[i]) of chain chain[i] at period index period[i]
+ * (NaN for a query whose chain is outside [0, B) or whose period is outside
+ * [0, n_periods): the indices live on the device, the host cannot check them).
+ * The value is the one every search of the library sees at that abscissa, bit
+ * for bit.  Replaces nothing the reference calls directly; it is disba's dltar4 / dltar1
  * reached through src/inversion/model_params.py:201-206.
  */
 int mhd_secular_batch(const mhd_problem_t *prob, const double *params /* device [B,NP] */,
                       int32_t B, const int32_t *chain /* device [N] */,
                       const int32_t *period /* device [N] */, const double *c /* device [N] */,
                       int32_t N, double *delta /* device [N] */, void *stream);
+
+/*
+ * The same queries, two abscissae each, through the library's other inlined copy
+ * of the period equation (two abscissae per lane, as the verification pass of
+ * the period-parallel search evaluates them): delta[2i], delta[2i+1] =
+ * Delta(c[2i]), Delta(c[2i+1]) of chain chain[i] at period period[i].  A test
+ * hook: both copies must return the same bits as mhd_secular_batch, or searches
+ * that reach an abscissa through different copies could disagree on a sign next
+ * to a root.  No counterpart in the reference.
+ */
+int mhd_debug_secular_pairs(const mhd_problem_t *prob, const double *params /* device [B,NP] */,
+                            int32_t B, const int32_t *chain /* device [N] */,
+                            const int32_t *period /* device [N] */,
+                            const double *c /* device [N,2] */, int32_t N,
+                            double *delta /* device [N,2] */, void *stream);
 
 /*
  * DispersionCurveParams.forward_model for B parameter vectors

@@ -30,6 +30,7 @@ EXPORTS = (
     "mhd_sched_bytes",
     "mhd_sched_min_steps",
     "mhd_secular_batch",
+    "mhd_debug_secular_pairs",
     "mhd_forward_batch",
     "mhd_loglik_batch",
     "mhd_mh_steps",
@@ -102,6 +103,7 @@ def lib():
     L.mhd_sched_bytes.restype = ctypes.c_size_t
     L.mhd_secular_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                     c_void_p, c_void_p]
+    L.mhd_debug_secular_pairs.argtypes = L.mhd_secular_batch.argtypes
     L.mhd_forward_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
     L.mhd_loglik_batch.argtypes = [pp, c_void_p, c_int32, c_void_p, c_void_p]
     L.mhd_sched_min_steps.argtypes = []

@@ -104,6 +104,38 @@ __global__ __launch_bounds__(64) MHD_REGS void secular_kernel(mhd_problem_t p, c
     if (lane == 0) delta[q] = d;
 }
 
+// The same query through the evaluation of two abscissae per lane (the verification pass's):
+// c and delta hold two values per query.
+__global__ __launch_bounds__(64) MHD_REGS void secular_pair_kernel(
+    mhd_problem_t p, const double* params, int B, const int32_t* chain, const int32_t* period,
+    const double* c, int N, double* delta)
+{
+    LayerTable& T = g_T;
+    if ((threadIdx.x & 63) == 0) {
+        g_PS.prof_slot = (int)blockIdx.x;
+        g_PS.abort = 0;
+    }
+    __shared__ double m[MAXNP];
+    const int q = blockIdx.x;
+    if (q >= N) return;
+    const int lane = threadIdx.x;
+    const int NP = 2 * p.n_layers + 1;
+    const int ib = chain[q], ip = period[q];
+    if (ib < 0 || ib >= B || ip < 0 || ip >= p.n_periods) {
+        if (lane == 0) delta[2 * q] = delta[2 * q + 1] = __builtin_nan("");
+        return;
+    }
+    if (lane < NP) m[lane] = params[(size_t)ib * NP + lane];
+    __syncthreads();
+    build_layer_table(T, m, layers_of(p, ib), p.vpvs, lane, p.n_layers);
+    const double omega = TWOPI / p.periods[ip];
+    const SecVal2 v = eval_secular2(p.wave, omega, c[2 * q], omega, c[2 * q + 1]);
+    if (lane == 0) {
+        delta[2 * q] = v.m0;
+        delta[2 * q + 1] = v.m1;
+    }
+}
+
 __global__ __launch_bounds__(64) MHD_REGS void forward_kernel(mhd_problem_t p, const double* params, int B,
                                                      double* vel, int32_t* status,
                                                      unsigned long long* n_evals, int search)
@@ -184,10 +216,18 @@ __device__ inline void cov_accumulate_wave(const mhd_chains_t& ch, int ib, int N
 // start of the launch, d_* what the launch has added so far.  Called by the chain's first wave.
 __device__ inline void record_diag(const mhd_diag_t& dg, const mhd_chains_t& ch, int B, int ib,
                                    int NP, size_t h, const long long* base, int d_acc, int d_rej,
-                                   int d_bnd, int d_fm, int lane)
+                                   int d_bnd, int d_fm, int lane, long long d_lit = 0)
 {
     if (dg.hist_counters && lane < 5) {
-        const int d = lane == 0 ? d_acc : (lane == 1 ? d_rej : (lane == 2 ? d_bnd : (lane == 4 ? d_fm : 0)));
+        // (slot 3, the reference's n_physics_err, stays 0: no proposal of this parameterisation
+        // fails that check.  MHD_LIT_DEBUG, a debugging build: the sequential algorithm's
+        // evaluations of the chain so far in this launch instead)
+        long long d = lane == 0 ? d_acc : (lane == 1 ? d_rej : (lane == 2 ? d_bnd : (lane == 4 ? d_fm : 0)));
+#ifdef MHD_LIT_DEBUG
+        if (lane == 3) d = d_lit;
+#else
+        (void)d_lit;
+#endif
         dg.hist_counters[(h * B + ib) * 5 + lane] = base[lane] + (long long)d;
     }
     if (dg.hist_counters_ind && ch.counters_ind) {
@@ -1156,7 +1196,8 @@ again:
             if (hist_logL && lane == 0) hist_logL[h * B + ib] = logL;
             if (hist_pred)
                 for (int k = lane; k < ND; k += 64) hist_pred[(h * B + ib) * ND + k] = pred[k];
-            record_diag(dg, ch, B, ib, NP, h, cbase_[g], c_acc, c_rej, c_bnd, c_fm, lane);
+            record_diag(dg, ch, B, ib, NP, h, cbase_[g], c_acc, c_rej, c_bnd, c_fm, lane,
+                        (long long)lit);
         }
     };
     // the start of step j: update_covariance_matrix sees the state the step starts from
@@ -1534,6 +1575,9 @@ again:
             c5[1] += c_rej;
             c5[2] += c_bnd;
             c5[4] += c_fm;
+#ifdef MHD_LIT_DEBUG
+            c5[3] += (int64_t)lit;
+#endif
             if (n_evals) atomicAdd(&n_evals[0], lit);
         }
         if (n_evals) atomicAdd(&n_evals[1], exec);
@@ -1756,6 +1800,20 @@ int mhd_secular_batch(const mhd_problem_t* prob, const double* params, int32_t B
                        chain, period, c, N, delta);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_secular_batch launch");
+}
+
+int mhd_debug_secular_pairs(const mhd_problem_t* prob, const double* params, int32_t B,
+                            const int32_t* chain, const int32_t* period, const double* c,
+                            int32_t N, double* delta, void* stream)
+{
+    if (int rc = check_problem(prob, false)) return rc;
+    if (B < 0 || N < 0) return fail(MHD_EINVAL, "negative size");
+    if (N == 0) return MHD_OK;
+    if (!params || !chain || !period || !c || !delta) return fail(MHD_EINVAL, "NULL argument");
+    hipLaunchKernelGGL(secular_pair_kernel, dim3(N), dim3(64), WAVE_LDS_BYTES, (hipStream_t)stream,
+                       *prob, params, B, chain, period, c, N, delta);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MHD_OK : hip_fail(e, "mhd_debug_secular_pairs launch");
 }
 
 int mhd_forward_batch(const mhd_problem_t* prob, const double* params, int32_t B, double* vel,

@@ -946,6 +946,11 @@ __device__ __forceinline__ int solve_period_impl(int wave, double t1, double& c1
             ++dctrl;
         }
         if (!settled) continue;  // more than 7 halvings left: by another tree round
+        // An answer above the ceiling ends the curve ("no root") at once, before anything could
+        // verify the tail it was inferred from: that verdict is only given on evaluated halvings.
+        // (An inferred answer below the ceiling whose true one lies above is caught like any
+        // wrong tail: the period is searched again, and fails then.)
+        if (!uni(d3 <= betmx)) continue;
         wave_sync();
         if (lane >= 57 && lane - 57 < n) {
             T.pend_x[lane - 57] = px;

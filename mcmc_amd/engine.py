@@ -154,6 +154,21 @@ class DeviceProblem:
                                               _stream(self.device)))
         return delta
 
+    def secular_pairs(self, params, chain, period, c):
+        """c [N,2] -> [N,2]: the same values as secular() through the evaluation of two
+        abscissae per lane (mhd_debug_secular_pairs)."""
+        params = params.contiguous()
+        N = chain.numel()
+        assert chain.dtype == torch.int32 and period.dtype == torch.int32 and period.numel() == N
+        assert c.dtype == torch.float64 and c.shape == (N, 2)
+        chain, period, c = chain.contiguous(), period.contiguous(), c.contiguous()
+        delta = torch.empty((N, 2), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().mhd_debug_secular_pairs(self.cref(), _ptr(params), params.shape[0],
+                                                    _ptr(chain), _ptr(period), _ptr(c), N,
+                                                    _ptr(delta), _stream(self.device)))
+        return delta
+
     # -- Model.get_likelihood for a batch (src/inversion/model.py:420-447) --
     def loglik(self, pred):
         pred = pred.contiguous()

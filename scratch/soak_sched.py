@@ -1,8 +1,9 @@
 """Soak of the launch schedule: random numbers of chains (odd ones too), call lengths on both
 sides of the two-launch threshold, layers, periods, rotated proposals, tempering betas -- the
-chains of scheduled calls must equal those of the same calls without the schedule, bit for bit
+chains of scheduled calls (through mhd_mh_steps and through mhd_mh_steps_static) must equal those
+of the same calls without the schedule, bit for bit
 (states, likelihoods, curves, counters, decisions, history, literal evaluation count), and no
-wait between waves may have timed out.  usage: soak_sched.py [configurations]"""
+wait between waves may have timed out.  usage: soak_sched.py [configurations] [first configuration]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -45,20 +46,27 @@ for r in range(first, first + n_cfg):
     ua = torch.tensor(rng.uniform(size=(S, B)), device=dev)
     rot = torch.tensor(np.stack([np.linalg.qr(rng.standard_normal((NP, NP)))[0] for _ in range(B)]), device=dev) if rotate else None
     res = []
-    for scheduled in (True, False):
+    # the caller's schedule buffer; none (one launch per call); the library's static buffer
+    for scheduled in (True, False, "static"):
         ch = DeviceChains(prob, starts, 0.05, beta=None if beta is None else torch.tensor(beta, device=dev))
         if not scheduled:
             ch.sched = None
+        if scheduled == "static":
+            L.check(L.lib().mhd_static_reset(None))
         if rot is not None:
             ch.rot.copy_(rot)
         assert int((ch.init_likelihood() != 0).sum()) == 0
         outs, a = [], 0
         for n in calls:
-            o = ch.steps(idx[a:a + n], cz[a:a + n], ua[a:a + n], rotate=rotate, hist_every=max(1, n // 3))
+            o = ch.steps(idx[a:a + n], cz[a:a + n], ua[a:a + n], rotate=rotate, hist_every=max(1, n // 3),
+                         static_scratch=scheduled == "static")
             outs.append(torch.cat([o["accepted"].flatten().double(), o["status"].flatten().double(), o["hist_logL"].flatten(), o["hist_m"].flatten()]))
             a += n
         res.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(), torch.cat(outs), int(ch.n_evals[0])))
     ok = all(torch.equal(x, y) for x, y in zip(res[0][:5], res[1][:5])) and res[0][5] == res[1][5]
+    if not (all(torch.equal(x, y) for x, y in zip(res[2][:5], res[1][:5])) and res[2][5] == res[1][5]):
+        ok = False
+        print("   (the static entry point differs)")
     tag = "nl %d P %d B %d %s rot %d beta %d calls %s" % (nl, P, B, itype, rotate, beta is not None, calls)
     if not ok:
         bad += 1

@@ -47,6 +47,26 @@ def main():
     # the sabotage is at work: the product build executes ~7.6 evaluations per sequential one
     assert execs[1] > 9.0 * olit, (execs, olit)
 
+    # A 3-layer model whose root at the 13th period lies just under the ceiling (the largest
+    # layer velocity) and whose 14th period has none.  The bracket of the 13th straddles the
+    # ceiling, so an answer inferred from a wrong root can lie above it: "no root" must not be
+    # said on an inferred answer (the deferring search once did, one period early).
+    m13 = np.array([float.fromhex(v) for v in (
+        "0x1.40edce5fc6e56p-8", "0x1.b1191cf2c4ff1p-8", "0x1.f8fc5e970f1d3p-6",
+        "0x1.7c6752b8e9f87p+0", "0x1.e001947c78776p-1", "0x1.0c693717137adp+0",
+        "0x1.a19149b61738ap-2")])
+    for n_per, want_st in ((13, 0), (14, 3), (40, 3)):
+        o_st, o_vel, o_lit = oracle.forward(m13, 3, 1.75, periods[:n_per])
+        assert o_st == want_st
+        for search in (1, 2):
+            prob = DeviceProblem(3, 1.75, periods[:n_per], search=search)
+            ne = torch.zeros(2, dtype=torch.int64, device=prob.device)
+            vel, st = prob.forward(torch.tensor(m13[None], device=prob.device), n_evals=ne)
+            assert st.tolist() == [o_st] and int(ne[0]) == o_lit, (n_per, search, st.tolist(),
+                                                                  int(ne[0]), o_lit)
+            if o_st == 0:
+                assert np.array_equal(vel[0].cpu().numpy(), o_vel)
+
     # MH steps with the wave-sequential and the predicted search
     bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
     good = params[ost == 0][:64]

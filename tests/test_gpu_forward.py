@@ -125,6 +125,42 @@ def test_model_with_a_halving_abscissa_next_to_a_root(torch_cuda, oracle):
     assert d > 0 and od > 0 and d < 1e-10
 
 
+@pytest.mark.parametrize("wave", ["rayleigh", "love"])
+def test_both_copies_of_the_period_equation_return_the_same_bits(torch_cuda, wave):
+    """The period equation is inlined twice -- one abscissa per lane (mhd_secular_batch, the
+    predictors, the wave-sequential search) and two per lane (the verification pass): 32 768
+    abscissae of 64 models with low-velocity zones, pairs on the same side of the layer
+    velocities and pairs that straddle one, next to roots and away from them."""
+    torch = torch_cuda
+    from mcmc_amd.engine import DeviceProblem
+    rng = np.random.default_rng(17)
+    nl, P, B, N = 6, 40, 64, 16384
+    periods = np.flip(1 / np.logspace(0.0, 1.3, P)).copy()
+    params = prior_draws(rng, B, nl)
+    prob = DeviceProblem(nl, 1.75, periods, wave=wave)
+    dev = prob.device
+    chain = torch.tensor(rng.integers(0, B, N).astype(np.int32), device=dev)
+    per = torch.tensor(rng.integers(0, P, N).astype(np.int32), device=dev)
+    c = rng.uniform(0.08, 2.2, (N, 2))
+    c[: N // 2, 1] = c[: N // 2, 0] + rng.uniform(-0.005, 0.005, N // 2)   # neighbours of a search
+    # a quarter of them next to a root: the curve's own velocities, a few ulps off
+    vel, st = prob.forward(torch.tensor(params, device=dev))
+    vel, st = vel.cpu().numpy(), st.cpu().numpy()
+    q = np.arange(N // 4)
+    ok = st[chain.cpu().numpy()[q]] == 0
+    root = vel[chain.cpu().numpy()[q], per.cpu().numpy()[q]]
+    c[q[ok], 0] = root[ok] * (1 + rng.integers(-8, 9, ok.sum()) * 2.0 ** -52)
+    c[q[ok], 1] = root[ok] * (1 + rng.integers(-8, 9, ok.sum()) * 2.0 ** -40)
+    ct = torch.tensor(c, device=dev)
+    p_t = torch.tensor(params, device=dev)
+    pair = prob.secular_pairs(p_t, chain, per, ct).cpu().numpy()
+    one = np.stack([prob.secular(p_t, chain, per, ct[:, j].contiguous()).cpu().numpy()
+                    for j in (0, 1)], axis=1)
+    assert np.isfinite(one).all()
+    np.testing.assert_array_equal(pair.view(np.int64), one.view(np.int64))
+    assert (np.sign(one[:, 0]) != np.sign(one[:, 1])).mean() > 0.05     # both signs occur
+
+
 def test_secular_query_outside_the_batch_answers_nan(torch_cuda):
     """mhd_secular_batch reads its chain and period indices on the device: one that points
     outside the batch or the periods gives NaN for that query, the others are answered."""
