@@ -11,6 +11,20 @@ import torch
 from mcmc_amd import _lib as L
 from mcmc_amd.engine import DeviceChains, DeviceProblem
 
+# what a call does not write stays recognisable: the outputs start as NaN / 77 instead of whatever
+# the allocator hands out (two runs could otherwise agree on an unwritten entry by getting the same
+# block of memory back)
+import mcmc_amd.engine as _E
+class _PoisonedTorch:
+    def __getattr__(self, name):
+        if name != "empty":
+            return getattr(torch, name)
+        def empty(*a, **k):
+            t = torch.empty(*a, **k)
+            return t.fill_(float("nan") if t.is_floating_point() else 77)
+        return empty
+_E.torch = _PoisonedTorch()
+
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0
@@ -45,10 +59,31 @@ for r in range(first, first + n_cfg):
     cz = torch.tensor(np.tan(np.pi * (rng.uniform(size=(S, B)) - 0.5)), device=dev)
     ua = torch.tensor(rng.uniform(size=(S, B)), device=dev)
     rot = torch.tensor(np.stack([np.linalg.qr(rng.standard_normal((NP, NP)))[0] for _ in range(B)]), device=dev) if rotate else None
+    # every seventh configuration mixes layer counts (rows padded to nl; no rotation with those):
+    # drawn from a generator of its own, so that the other configurations stay what they were
+    nb = None
+    if r % 7 == 5 and nl >= 3:
+        rng2 = np.random.default_rng(19000 + r)
+        rotate, rot = 0, None
+        rows, nb = np.empty((0, NP)), np.empty(0, dtype=np.int32)
+        while rows.shape[0] < B:
+            n_c = rng2.integers(1, nl + 1, 2 * B).astype(np.int32)
+            cand = np.full((2 * B, NP), 0.777)
+            for i, n in enumerate(n_c):
+                cand[i, :n] = np.sort(rng2.uniform(0.001, 0.15, n))
+                cand[i, nl:nl + n + 1] = np.sort(rng2.uniform(0.1, 2.0, n + 1))
+            _, st = prob0.forward(torch.tensor(cand, device=dev), n_layers_b=n_c)
+            good = st.cpu().numpy() == 0
+            rows, nb = np.concatenate([rows, cand[good]]), np.concatenate([nb, n_c[good]])
+        rows, nb = rows[:B], nb[:B].astype(np.int32)
+        starts = rows
+        jj = rng2.integers(0, 2 ** 31, (S, B))
+        ic = jj % (2 * nb[None, :] + 1)
+        idx = torch.tensor(np.where(ic < nb[None, :], ic, nl + ic - nb[None, :]).astype(np.int32), device=dev)
     res = []
     # the caller's schedule buffer; none (one launch per call); the library's static buffer
     for scheduled in (True, False, "static"):
-        ch = DeviceChains(prob, starts, 0.05, beta=None if beta is None else torch.tensor(beta, device=dev))
+        ch = DeviceChains(prob, starts, 0.05, beta=None if beta is None else torch.tensor(beta, device=dev), n_layers_b=nb)
         if not scheduled:
             ch.sched = None
         if scheduled == "static":
@@ -61,13 +96,14 @@ for r in range(first, first + n_cfg):
             o = ch.steps(idx[a:a + n], cz[a:a + n], ua[a:a + n], rotate=rotate, hist_every=max(1, n // 3),
                          static_scratch=scheduled == "static")
             outs.append(torch.cat([o["accepted"].flatten().double(), o["status"].flatten().double(), o["hist_logL"].flatten(), o["hist_m"].flatten()]))
+            assert not bool(torch.isnan(outs[-1]).any()) and not bool((o["accepted"] == 77).any()), "an output was not written"
             a += n
         res.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(), torch.cat(outs), int(ch.n_evals[0])))
     ok = all(torch.equal(x, y) for x, y in zip(res[0][:5], res[1][:5])) and res[0][5] == res[1][5]
     if not (all(torch.equal(x, y) for x, y in zip(res[2][:5], res[1][:5])) and res[2][5] == res[1][5]):
         ok = False
         print("   (the static entry point differs)")
-    tag = "nl %d P %d B %d %s rot %d beta %d calls %s" % (nl, P, B, itype, rotate, beta is not None, calls)
+    tag = "nl %d%s P %d B %d %s rot %d beta %d calls %s" % (nl, "" if nb is None else " (mixed)", P, B, itype, rotate, beta is not None, calls)
     if not ok:
         bad += 1
         names = ["m", "logL", "pred", "counters", "flags+history"]
