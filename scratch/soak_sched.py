@@ -39,7 +39,15 @@ for r in range(first, first + n_cfg):
     calls = [int(x) for x in rng.choice([3, 7, 12, 20, 30, 47, 48, 60, 90, 130], size=int(rng.integers(3, 6)))]
     periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
     bounds = np.array([[0.001, 0.15, 0.149]] * nl + [[0.1, 2.0, 1.9]] * (nl + 1))
-    prob0 = DeviceProblem(nl, 1.75, periods, itype=itype)
+    # (from a generator of its own, so that the configurations stay what they were: the wave
+    # type, the search, the candidates in flight where the schedule leaves the choice, the
+    # likelihood)
+    # (configurations below 6000 are the plain ones of the earlier runs: Rayleigh waves, the
+    # default search and candidates, the normal likelihood)
+    rng3 = np.random.default_rng(29000 + r)
+    vary = r >= 6000
+    wave = "love" if vary and itype in ("phase", "group") and rng3.uniform() < 0.2 else "rayleigh"
+    prob0 = DeviceProblem(nl, 1.75, periods, itype=itype, wave=wave)
     starts = np.empty((0, NP))
     while starts.shape[0] < B:
         cand = rng.uniform(bounds[:, 0], bounds[:, 1], size=(2 * B, NP))
@@ -51,7 +59,13 @@ for r in range(first, first + n_cfg):
     starts = starts[:B]
     true = prob0.forward(torch.tensor(starts[:1], device=prob0.device))[0][0].cpu().numpy()
     obs = true + 0.03 * rng.standard_normal(true.shape[0])
-    prob = DeviceProblem(nl, 1.75, periods, obs, "normal", {"std": 0.03}, bounds, itype=itype)
+    srch = int(rng3.choice([0, 0, 0, 0, 1])) if vary else 0
+    cands = int(rng3.choice([0, 0, 0, 4, 1])) if vary else 0
+    if vary and rng3.uniform() < 0.25:
+        noise = ("asym-laplace", {"lambd": rng3.uniform(20.0, 60.0, true.shape[0]), "lambd_scale": 1.0, "kappa": rng3.uniform(0.6, 1.6, true.shape[0])})
+    else:
+        noise = ("normal", {"std": 0.03})
+    prob = DeviceProblem(nl, 1.75, periods, obs, noise[0], noise[1], bounds, itype=itype, wave=wave, search=srch, candidates=cands)
     dev = prob.device
     beta = rng.uniform(0.05, 1.0, B) if rng.uniform() < 0.4 else None
     S = sum(calls)
@@ -103,7 +117,7 @@ for r in range(first, first + n_cfg):
     if not (all(torch.equal(x, y) for x, y in zip(res[2][:5], res[1][:5])) and res[2][5] == res[1][5]):
         ok = False
         print("   (the static entry point differs)")
-    tag = "nl %d%s P %d B %d %s rot %d beta %d calls %s" % (nl, "" if nb is None else " (mixed)", P, B, itype, rotate, beta is not None, calls)
+    tag = "nl %d%s P %d B %d %s %s %s search %d cand %d rot %d beta %d calls %s" % (nl, "" if nb is None else " (mixed)", P, B, itype, wave, noise[0], srch, cands, rotate, beta is not None, calls)
     if not ok:
         bad += 1
         names = ["m", "logL", "pred", "counters", "flags+history"]
