@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MHD_ABI_VERSION 7
+#define MHD_ABI_VERSION 8
 
 #define MHD_OK 0
 #define MHD_EINVAL (-22) /* bad argument (size beyond a compiled limit, NULL pointer) */
@@ -221,6 +221,17 @@ int mhd_init(int32_t device);
  * for the device anyway.  No counterpart in the reference.
  */
 int mhd_wait_timeouts(uint64_t *count);
+
+/*
+ * How many accept tests u <= exp(dl) (src/inversion/model.py:449-467) have been
+ * settled on the current device, since the library was loaded, with u within 16
+ * units in the last place of exp(dl).  The device's exponential and numpy's may
+ * differ by a unit or two in the last place, so only such a decision could come
+ * out differently in the reference; the library counts them instead of leaving
+ * the question open (one in some 1e14 steps is expected).  Synchronous, like
+ * mhd_wait_timeouts.  No counterpart in the reference.
+ */
+int mhd_close_decisions(uint64_t *count);
 
 /*
  * Resident workgroups per compute unit of the one-candidate MH kernel and of the

@@ -311,6 +311,16 @@ __device__ __forceinline__ void hint_limit_update(float* limit, int kk, double c
 #define ADOPT_MIN_STEPS 2
 #endif
 #endif
+// Accept tests u <= exp(dl) that were settled with u within CLOSE_ULPS units in the last place of
+// exp(dl) (mhd_close_decisions): two correctly working exponentials may differ by a unit or two
+// there, so only such a decision could come out differently with the reference's numpy.
+__device__ unsigned long long g_close_decisions;
+constexpr double CLOSE_ULPS = 16.0;
+__device__ __forceinline__ bool close_decision(double u, double e)
+{
+    // (u = 0 passes whatever the exponential gives, and an infinite one passes every u)
+    return u > 0.0 && e < 1.0e308 && fabs(u - e) <= CLOSE_ULPS * 2.220446049250313e-16 * e;
+}
 struct SearchPolicy {
     int level, left;
     int max_level;  // 3, or 0 where the predictor has the chain's current curve to go by: there
@@ -503,7 +513,9 @@ __global__ __launch_bounds__(64) MHD_REGS void mh_steps_kernel(
             double dl = lnew - logL;
             dl = dl / Temp;
             if (ch.beta) dl = beta * dl;
-            acc = ua <= exp(dl);
+            const double edl = exp(dl);
+            acc = ua <= edl;
+            if (lane == 0 && close_decision(ua, edl)) atomicAdd(&g_close_decisions, 1ull);
             if (acc) {
                 if (lane < NP) {
                     ch.params_prev[(size_t)ib * NP + lane] = mn[lane];
@@ -1206,11 +1218,15 @@ again:
             cov_accumulate_wave(ch, ib, NP, mn, tmp[w0], lane);
     };
     // accept test (model.py:449-467) of a candidate for step j with likelihood lnew
-    auto accept_test = [&](double lnew, int j) -> int {
+    // (settling: the test decides a step of the chain, not only which curves are given up)
+    auto accept_test = [&](double lnew, int j, bool settling) -> int {
         double dl = lnew - logL;
         dl = dl / Temp;
         if (ch.beta) dl = beta * dl;
-        return __builtin_amdgcn_readfirstlane((int)(u_acc[(size_t)j * B + ib] <= exp(dl)));
+        const double u = u_acc[(size_t)j * B + ib], edl = exp(dl);
+        if (settling && writer && lane == 0 && close_decision(u, edl))
+            atomicAdd(&g_close_decisions, 1ull);
+        return __builtin_amdgcn_readfirstlane((int)(u <= edl));
     };
     // the candidate of wave c settles step j: the accept test and, if it passes, the move
     auto settle = [&](int c, int j) -> int {
@@ -1218,7 +1234,7 @@ again:
         int acc = 0;
         if (st == MHD_ST_OK) {
             const double lnew = r_logL[c];
-            acc = accept_test(lnew, j);
+            acc = accept_test(lnew, j, true);
             if (acc) {
                 if (writer) {
                     if (lane < NP) {
@@ -1386,7 +1402,7 @@ again:
             // rejected is moot -- if it is reached it is accepted, if not, an earlier one was.
             // Failed: whatever takes it to be accepted is moot, by the same argument.)
             if (ABORT_MOOT && nw > 1 && mybits == 0 && st != MHD_ST_ABORTED && !ABORT_SABOTAGE) {
-                const int out = (st == MHD_ST_OK) ? accept_test(lnew, jc) : 0;
+                const int out = (st == MHD_ST_OK) ? accept_test(lnew, jc, false) : 0;
 #pragma unroll
                 for (int q = 0; q < NW; ++q)
                     if (q != wi && q < nw && nlen[q] > mylen &&
@@ -1715,6 +1731,16 @@ int mhd_wait_timeouts(uint64_t* count)
     unsigned long long n = 0;
     const hipError_t e = hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wait_timeouts), sizeof(n));
     if (e != hipSuccess) return hip_fail(e, "mhd_wait_timeouts");
+    *count = (uint64_t)n;
+    return MHD_OK;
+}
+
+int mhd_close_decisions(uint64_t* count)
+{
+    if (!count) return fail(MHD_EINVAL, "count is NULL");
+    unsigned long long n = 0;
+    const hipError_t e = hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_close_decisions), sizeof(n));
+    if (e != hipSuccess) return hip_fail(e, "mhd_close_decisions");
     *count = (uint64_t)n;
     return MHD_OK;
 }

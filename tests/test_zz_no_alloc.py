@@ -41,6 +41,43 @@ def test_no_wait_between_waves_has_timed_out_in_the_tests_before():
     L.check_waits()
 
 
+def test_accept_decisions_near_the_threshold_are_counted():
+    """u <= exp(dl) is taken with the device's exponential where the reference takes it with
+    numpy's; the two may differ by a unit or two in the last place, so a decision with u within
+    16 units of exp(dl) is the only kind that could come out differently.  The library counts
+    them (mhd_close_decisions): none in everything the tests before this one ran in this
+    process, and every one of a batch of steps whose u is numpy's exp(dl) itself."""
+    import torch
+    from mcmc_amd import _lib as L
+    from mcmc_amd.engine import DeviceChains
+    torch.zeros(1, device="cuda")
+    assert L.close_decisions() == 0, "a parity test before this one had a decision within 16 ulps"
+    rng = np.random.default_rng(123)
+    B = 96
+    prob, starts = _problem(rng, B)
+    dev, NP = prob.device, 2 * NL + 1
+    idx = torch.tensor(rng.integers(0, NP, (1, B)).astype(np.int32), device=dev)
+    cauchy = torch.tensor(0.05 * np.tan(np.pi * (rng.uniform(size=(1, B)) - 0.5)), device=dev)
+    # first with a tiny u: nearly everything that has a curve is accepted, and leaves its likelihood behind
+    ch = DeviceChains(prob, starts, 0.05)
+    assert int((ch.init_likelihood() != 0).sum()) == 0
+    l_old = ch.logL.cpu().numpy().copy()
+    out = ch.steps(idx, cauchy, torch.full((1, B), 1e-300, dtype=torch.float64, device=dev))
+    dl = ch.logL.cpu().numpy() - l_old
+    moved = (out["accepted"][0].cpu().numpy() == 1) & (np.abs(dl) < 600.0)
+    assert moved.sum() > B // 4 and L.close_decisions() == 0
+    # then with u = exp(dl) by numpy, in both kernels that settle steps
+    u = np.where(moved, np.exp(dl), 0.5)
+    expect = 0
+    for candidates in (2, 1):
+        prob.candidates = candidates
+        ch = DeviceChains(prob, starts, 0.05)
+        assert int((ch.init_likelihood() != 0).sum()) == 0
+        ch.steps(idx, cauchy, torch.tensor(u[None, :], device=dev))
+        expect += int(moved.sum())
+        assert L.close_decisions() == expect
+
+
 def test_static_scratch_entry_point_matches_mhd_mh_steps():
     import torch
     from mcmc_amd.engine import DeviceChains
