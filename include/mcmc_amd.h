@@ -69,7 +69,9 @@ extern "C" {
 
 /* compiled limits */
 #define MHD_MAX_LAYERS 15   /* finite layers; rows = n_layers + 1 <= 16 */
+#ifndef MHD_MAX_PERIODS
 #define MHD_MAX_PERIODS 128
+#endif
 
 /* rotate flags of mhd_mh_steps */
 #define MHD_ROT_ACCUMULATE 1 /* update_covariance_matrix before proposing  */

@@ -699,6 +699,11 @@ __host__ __device__ inline float sched_consumed(int nw, float p)
     return 1.0f + p + p * p + p * p * p;                        // A AA AAA
 }
 
+#ifdef MHD_ABORT_SABOTAGE
+constexpr bool ABORT_SABOTAGE_BUILD = true;
+#else
+constexpr bool ABORT_SABOTAGE_BUILD = false;
+#endif
 struct SchedView {
     float* cost;  // [B]
     int* n4;      // [0] n4, [1] n1: workgroups of four one-candidate chains, [2..3] the deadline of the launch,
@@ -712,10 +717,21 @@ struct SchedView {
                            // 63rds (0: not known yet), see mh_steps_multi_kernel
 };
 
-__host__ __device__ inline int sched_cap4(int B, int phase)
+#ifndef SCHED_FREE4
+#define SCHED_FREE4 1
+#endif
+// Chains that can have four candidates without another chain paying for it: the wave slots
+// the GPU has beyond two per chain, two more per such chain.
+__host__ __device__ inline int sched_free4(int B, int slots)
 {
-    const int c = phase == 0 ? B / 8 : B / 2;
-    return c > 0 ? c : 1;
+    const int f = SCHED_FREE4 ? (slots - 2 * B) / 2 : 0;
+    return f < 0 ? 0 : (f > B ? B : f);
+}
+
+__host__ __device__ inline int sched_cap4(int B, int phase, int slots)
+{
+    const int c = (phase == 0 ? B / 8 : B / 2) + sched_free4(B, slots);
+    return c > B ? B : (c > 0 ? c : 1);
 }
 
 __host__ __device__ inline SchedView sched_view(void* buf, int B)
@@ -817,10 +833,17 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
             const float p = sched_pacc(v, val[j]);
             return key[j] * sched_consumed(2, p) / sched_consumed(4, p);
         };
+        // (wave slots beyond two per chain go to the chains at the head of the order, two more
+        // each, whatever is known about them)
+        // (the test build gives only half of them away, so that its launches mix every kind of
+        // workgroup)
+        const int free4 = sched_free4(B, slots) / (ABORT_SABOTAGE_BUILD ? 2 : 1);
+        if (unknown) n4 = free4;
         if (!unknown && phase == 0) {
             // four candidates for the chains that stand out from the others; each takes two
             // wave slots more, which two of the cheapest chains give up
-            const int cap = sched_cap4(B, 0);
+            const int cap = sched_cap4(B, 0, slots);
+            n4 = free4;
 #ifdef MHD_ABORT_SABOTAGE
             const bool whatever_they_cost = true;  // the test build runs every kind of workgroup
 #else
@@ -828,10 +851,11 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
 #endif
             // (with more chains than the GPU holds at once the launch is a queue of
             // two-candidate workgroups in this order: whoever finishes makes room)
-            while (2 * B <= slots && n4 < cap && n4 < SCHED_FOUR_MAX(B) && 4 * n4 + 8 < B &&
-                   (whatever_they_cost || key[n4] > SCHED_FOUR_ABOVE * key[B / 2]))
+            while (2 * B <= slots && n4 < cap && n4 - free4 < SCHED_FOUR_MAX(B) &&
+                   4 * (n4 - free4) + 8 < B - free4 &&
+                   (whatever_they_cost || key[n4] > SCHED_FOUR_ABOVE * key[(B + free4) / 2]))
                 ++n4;
-            n1 = (n4 + 1) / 2;
+            n1 = (n4 - free4 + 1) / 2;
             if (PHASE_DEADLINE_FRACTION > 0.0f && phases > 1 && tick > 0.0f)
                 deadline = (unsigned long long)wall_clock64() +
                            (unsigned long long)(PHASE_DEADLINE_FRACTION * key[B / 2] * (float)S *
@@ -846,9 +870,9 @@ __global__ __launch_bounds__(1024) void schedule_kernel(void* buf, int B, int S,
             v.n4[5] = left;
             // (SCHED_LATER_FOUR 0: none -- the chains with most work left share their workgroups
             // with the finished ones and take their waves on at once, see mh_steps_multi_kernel)
-            const int room = (2 * B > slots || !SCHED_LATER_FOUR) ? 0 : (slots - 2 * left) / 2;
+            const int room = 2 * B > slots ? 0 : (SCHED_LATER_FOUR ? (slots - 2 * left) / 2 : free4);
             n4 = room < 0 ? 0 : (room < left ? room : left);
-            const int cap = sched_cap4(B, phase);
+            const int cap = sched_cap4(B, phase, slots);
             if (n4 > cap) n4 = cap;
             if (phase < phases - 1 && left > 0 && tick > 0.0f)
                 deadline = (unsigned long long)wall_clock64() +
@@ -1897,7 +1921,7 @@ static int mh_steps_enqueue(const mhd_problem_t* prob, const mhd_chains_t* chain
         // one launch per phase, of workgroups of four waves that hold one, two or four chains
         // (schedule_kernel says which); the grid covers the most workgroups a phase can need,
         // those beyond what it does need return at once
-        const int slots = sd->cus * 8;  // two waves of these kernels per SIMD
+        const int slots = sd->cus * 4 * MHD_WAVES_PER_SIMD;  // waves of these kernels the GPU holds
         // (a short call is one launch, see SCHED_MIN_STEPS)
         const int phases = n_steps >= SCHED_PHASES_MIN_STEPS ? SCHED_PHASES : 1;
         for (int phase = 0; phase < phases; ++phase) {
@@ -1912,8 +1936,8 @@ static int mh_steps_enqueue(const mhd_problem_t* prob, const mhd_chains_t* chain
                                    hist_logL, hist_pred, dg, ne, search, 1);
                 continue;
             }
-            const int cap = sched_cap4(B, phase);
-            const int grid = phase == 0 ? B / 2 + 2 : cap + (B - cap + 1) / 2 + 1;
+            const int cap = sched_cap4(B, phase, slots);
+            const int grid = cap + (B - cap + 1) / 2 + 2;
             hipLaunchKernelGGL(mh_steps_multi_kernel<4>, dim3(grid), dim3(256),
                                4 * WAVE_LDS_BYTES, s, *prob, *chains, B, n_steps, idx, cauchy,
                                u_acc, T, rotate, accepted, status, hist_every, hist_m, hist_logL,

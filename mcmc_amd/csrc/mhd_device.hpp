@@ -52,7 +52,10 @@ struct LayerTable {
 
 // Out-of-line routines share one register budget: VGPRs + AGPRs <= 256, so that two waves fit
 // on a SIMD (512 registers per lane) and hide each other's FP64 latency.
-#define MHD_REGS __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef MHD_WAVES_PER_SIMD
+#define MHD_WAVES_PER_SIMD 2
+#endif
+#define MHD_REGS __attribute__((amdgpu_waves_per_eu(MHD_WAVES_PER_SIMD, MHD_WAVES_PER_SIMD)))
 #define MHD_NOINLINE __attribute__((noinline))
 
 // Scratch of one wave in dynamic LDS: the layer table of the model it works on, then the state
@@ -60,7 +63,10 @@ struct LayerTable {
 // with WAVE_LDS_BYTES of dynamic LDS per wave of its workgroups; the out-of-line routines reach
 // the instance of the calling wave through g_T / g_PS, with LDS instructions and no pointer
 // argument.
-constexpr int WAVE_LDS_BYTES = 9 * 1024;
+#ifndef MHD_WAVE_LDS_BYTES
+#define MHD_WAVE_LDS_BYTES (9 * 1024)
+#endif
+constexpr int WAVE_LDS_BYTES = MHD_WAVE_LDS_BYTES;
 constexpr int WAVE_LDS_SEARCH_OFFSET = (sizeof(LayerTable) + 15) / 16 * 16;
 extern __shared__ __align__(16) unsigned char mhd_wave_lds[];
 #define g_T (*reinterpret_cast<LayerTable*>(mhd_wave_lds + (threadIdx.x >> 6) * WAVE_LDS_BYTES))
