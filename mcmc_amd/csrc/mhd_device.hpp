@@ -57,6 +57,21 @@ struct LayerTable {
 #endif
 #define MHD_REGS __attribute__((amdgpu_waves_per_eu(MHD_WAVES_PER_SIMD, MHD_WAVES_PER_SIMD)))
 #define MHD_NOINLINE __attribute__((noinline))
+// Polynomial constants kept in registers across the layers of an evaluation (see
+// rayleigh_compound, secular_rayleigh2); 0: set up again in every layer.
+// MHD_PIN_K, one abscissa per lane: 4 all in scalar registers; 1 those of the written-out Horner
+// steps in vector registers, 2 the others in vector registers too, 3 the others in scalar
+// registers.  (Measured: 3 makes the evaluation 3 % faster than 4 and the chains 1.5 %, but it
+// takes 80 vector registers from the callers, which then spill 75 instead of 19 of theirs: 3.3
+// instead of 0.2 GB of scratch traffic per 250 steps of 1024 chains.)
+// MHD_PIN_K2, two abscissae per lane (all constants in scalar registers there): 1 those of the
+// written-out Horner steps, 2 all.
+#ifndef MHD_PIN_K
+#define MHD_PIN_K 4
+#endif
+#ifndef MHD_PIN_K2
+#define MHD_PIN_K2 2
+#endif
 
 // Scratch of one wave in dynamic LDS: the layer table of the model it works on, then the state
 // of the predicted search (mhd_search2.hpp).  A kernel that calls the forward model is launched
@@ -119,7 +134,7 @@ __device__ __forceinline__ double uniform_value(double x)
 // ex = r*dpth when evanescent (0 otherwise).
 __device__ __forceinline__ void osc_or_evan(double k, double xk, double dpth, double& cs,
                                             double& over_r, double& times_r, double& em,
-                                            double& ex)
+                                            double& ex, const MathK* K = nullptr)
 {
     const double s2 = (k + xk) * fabs(k - xk);
     const double ir = rsqrt_pos(fmax(s2, 1.0e-300));
@@ -127,7 +142,7 @@ __device__ __forceinline__ void osc_or_evan(double k, double xk, double dpth, do
     const double arg = r * dpth;
     if (k < xk) {
         double s, c;
-        if (arg < 1.0e5) sincos_pio2(arg, s, c); else sincos(arg, &s, &c);
+        if (arg < 1.0e5) sincos_pio2<MHD_PIN_K == 4>(arg, s, c, K); else sincos(arg, &s, &c);
         cs = c;
         over_r = s * ir;
         times_r = -r * s;
@@ -140,7 +155,7 @@ __device__ __forceinline__ void osc_or_evan(double k, double xk, double dpth, do
         em = 1.0;
         ex = 0.0;
     } else {
-        em = exp_neg(fmin(arg, 700.0));
+        em = exp_neg<MHD_PIN_K == 4>(fmin(arg, 700.0), K);
         const double fac = (arg < 16.0) ? em * em : 0.0;
         cs = (1.0 + fac) * 0.5;
         const double sh = (1.0 - fac) * 0.5;
@@ -267,6 +282,37 @@ __device__ __forceinline__ double rayleigh_compound(const LayerTable& T, double 
                            T.rho[h], e0, e1, e2, e3, e4);
     }
     int sexp = 0;
+    // the polynomial constants in vector registers for all layers (the compiler is told not to
+    // hoist out of loops, see mcmc_amd/build.py, and would set them up again for every layer)
+#if MHD_PIN_K == 4
+    MathK KK = math_k();
+    asm volatile("" : "+s"(KK.s1), "+s"(KK.s2), "+s"(KK.s3), "+s"(KK.s4), "+s"(KK.c1), "+s"(KK.c2),
+                      "+s"(KK.c3), "+s"(KK.c4));
+    asm volatile("" : "+s"(KK.e3), "+s"(KK.e4), "+s"(KK.e5), "+s"(KK.e6), "+s"(KK.e7), "+s"(KK.e8),
+                      "+s"(KK.e9), "+s"(KK.e10), "+s"(KK.e11), "+s"(KK.e12));
+    asm volatile("" : "+s"(KK.inv_pio2), "+s"(KK.p1), "+s"(KK.p2), "+s"(KK.p3), "+s"(KK.s5), "+s"(KK.s6),
+                      "+s"(KK.c5), "+s"(KK.c6), "+s"(KK.log2e), "+s"(KK.ln2_hi), "+s"(KK.ln2_lo),
+                      "+s"(KK.e13));
+    const MathK* const K = &KK;
+#elif MHD_PIN_K > 0
+    MathK KK = math_k();
+    asm volatile("" : "+v"(KK.s1), "+v"(KK.s2), "+v"(KK.s3), "+v"(KK.s4), "+v"(KK.c1), "+v"(KK.c2),
+                      "+v"(KK.c3), "+v"(KK.c4));
+    asm volatile("" : "+v"(KK.e3), "+v"(KK.e4), "+v"(KK.e5), "+v"(KK.e6), "+v"(KK.e7), "+v"(KK.e8),
+                      "+v"(KK.e9), "+v"(KK.e10), "+v"(KK.e11), "+v"(KK.e12));
+#if MHD_PIN_K == 2
+    asm volatile("" : "+v"(KK.inv_pio2), "+v"(KK.p1), "+v"(KK.p2), "+v"(KK.p3), "+v"(KK.s5), "+v"(KK.s6),
+                      "+v"(KK.c5), "+v"(KK.c6), "+v"(KK.log2e), "+v"(KK.ln2_hi), "+v"(KK.ln2_lo),
+                      "+v"(KK.e13));
+#elif MHD_PIN_K == 3
+    asm volatile("" : "+s"(KK.inv_pio2), "+s"(KK.p1), "+s"(KK.p2), "+s"(KK.p3), "+s"(KK.s5), "+s"(KK.s6),
+                      "+s"(KK.c5), "+s"(KK.c6), "+s"(KK.log2e), "+s"(KK.ln2_hi), "+s"(KK.ln2_lo),
+                      "+s"(KK.e13));
+#endif
+    const MathK* const K = &KK;
+#else
+    const MathK* const K = nullptr;
+#endif
 
 #pragma nounroll
     for (int m = L - 2; m >= 0; --m) {
@@ -274,8 +320,8 @@ __device__ __forceinline__ double rayleigh_compound(const LayerTable& T, double 
         const double xkb = omega * T.inv_b[m];
         const double dpth = T.d[m];
         double cosp, w, x, ep, pex, cosq, y, z, eq, sex;
-        osc_or_evan(k, xka, dpth, cosp, w, x, ep, pex);
-        osc_or_evan(k, xkb, dpth, cosq, y, z, eq, sex);
+        osc_or_evan(k, xka, dpth, cosp, w, x, ep, pex, K);
+        osc_or_evan(k, xkb, dpth, cosq, y, z, eq, sex, K);
         (void)pex;
         (void)sex;
         compound_layer(k2, T.twob2[m] * inv_om2, T.rho[m], T.inv_rho[m], cosp, w, x, ep, cosq, y,
@@ -373,7 +419,7 @@ __device__ MHD_NOINLINE double eval_ellipticity(double omega, double c)
 // one-abscissa routine twice.
 __device__ __forceinline__ void osc_or_evan2(const double k[2], const double xk[2], double dpth,
                                              double cs[2], double over_r[2], double times_r[2],
-                                             double em[2], double ex[2])
+                                             double em[2], double ex[2], const MathK* K = nullptr)
 {
     const bool osc0 = k[0] < xk[0], osc1 = k[1] < xk[1];
     const bool ev0 = k[0] > xk[0], ev1 = k[1] > xk[1];
@@ -389,7 +435,7 @@ __device__ __forceinline__ void osc_or_evan2(const double k[2], const double xk[
         if (arg[0] < 1.0e5 && arg[1] < 1.0e5) {
             double sn[2], cn[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) sincos_pio2<true>(arg[u], sn[u], cn[u]);
+            for (int u = 0; u < 2; ++u) sincos_pio2<true>(arg[u], sn[u], cn[u], K);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 cs[u] = cn[u];
@@ -410,7 +456,7 @@ __device__ __forceinline__ void osc_or_evan2(const double k[2], const double xk[
             arg[u] = r[u] * dpth;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) e1[u] = exp_neg<true>(fmin(arg[u], 700.0));
+        for (int u = 0; u < 2; ++u) e1[u] = exp_neg<true>(fmin(arg[u], 700.0), K);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             em[u] = e1[u];
@@ -425,7 +471,7 @@ __device__ __forceinline__ void osc_or_evan2(const double k[2], const double xk[
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-        osc_or_evan(k[u], xk[u], dpth, cs[u], over_r[u], times_r[u], em[u], ex[u]);
+        osc_or_evan(k[u], xk[u], dpth, cs[u], over_r[u], times_r[u], em[u], ex[u], K);
 }
 
 __device__ __forceinline__ void secular_rayleigh2(const LayerTable& T, const double omega[2],
@@ -446,6 +492,22 @@ __device__ __forceinline__ void secular_rayleigh2(const LayerTable& T, const dou
             sexp[u] = 0;
         }
     }
+    // (the polynomial constants in scalar registers for all layers, see rayleigh_compound)
+#if MHD_PIN_K2 > 0
+    MathK KK = math_k();
+    asm volatile("" : "+s"(KK.s1), "+s"(KK.s2), "+s"(KK.s3), "+s"(KK.s4), "+s"(KK.c1), "+s"(KK.c2),
+                      "+s"(KK.c3), "+s"(KK.c4));
+    asm volatile("" : "+s"(KK.e3), "+s"(KK.e4), "+s"(KK.e5), "+s"(KK.e6), "+s"(KK.e7), "+s"(KK.e8),
+                      "+s"(KK.e9), "+s"(KK.e10), "+s"(KK.e11), "+s"(KK.e12));
+#if MHD_PIN_K2 > 1
+    asm volatile("" : "+s"(KK.inv_pio2), "+s"(KK.p1), "+s"(KK.p2), "+s"(KK.p3), "+s"(KK.s5), "+s"(KK.s6),
+                      "+s"(KK.c5), "+s"(KK.c6), "+s"(KK.log2e), "+s"(KK.ln2_hi), "+s"(KK.ln2_lo),
+                      "+s"(KK.e13));
+#endif
+    const MathK* const K = &KK;
+#else
+    const MathK* const K = nullptr;
+#endif
 #pragma nounroll
     for (int m = L - 2; m >= 0; --m) {
         const double ia = T.inv_a[m], ib = T.inv_b[m], tb2 = T.twob2[m];
@@ -457,8 +519,8 @@ __device__ __forceinline__ void secular_rayleigh2(const LayerTable& T, const dou
             xkb[u] = omega[u] * ib;
         }
         double cosp[2], w[2], x[2], ep[2], pex[2], cosq[2], y[2], z[2], eq[2], sex[2];
-        osc_or_evan2(k, xka, dpth, cosp, w, x, ep, pex);
-        osc_or_evan2(k, xkb, dpth, cosq, y, z, eq, sex);
+        osc_or_evan2(k, xka, dpth, cosp, w, x, ep, pex, K);
+        osc_or_evan2(k, xkb, dpth, cosq, y, z, eq, sex, K);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             compound_layer(k2[u], tb2 * inv_om2[u], rho1, irho, cosp[u], w[u], x[u], ep[u],

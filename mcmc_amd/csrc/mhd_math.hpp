@@ -54,39 +54,61 @@ MHD_HD double fma_k(double a, double b, double k)
 #endif
 }
 
+// The constants of the Horner steps that are written out as instructions (they must sit in
+// registers), for a caller that sets them up once before a loop instead of in every pass: with
+// K = nullptr the routines use their own literals, and the arithmetic is the same either way.
+struct MathK {
+    double s1, s2, s3, s4, c1, c2, c3, c4;
+    double e3, e4, e5, e6, e7, e8, e9, e10, e11, e12;
+    // the other constants that are no inline operands of the instruction set
+    double inv_pio2, p1, p2, p3, s5, s6, c5, c6, log2e, ln2_hi, ln2_lo, e13;
+};
+MHD_HD MathK math_k()
+{
+    return {-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+            2.75573137070700676789e-06, 4.16666666666666019037e-02, -1.38888888888741095749e-03,
+            2.48015872894767294178e-05, -2.75573143513906633035e-07,
+            1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0, 1.0 / 40320.0,
+            1.0 / 362880.0, 1.0 / 3628800.0, 1.0 / 39916800.0, 1.0 / 479001600.0,
+            6.36619772367581382433e-01, 1.57079632679489655800e+00, 6.12323399573676603587e-17,
+            -1.49738490485916983294e-33, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+            2.08757232129817482790e-09, -1.13596475577881948265e-11, 1.44269504088896338700e+00,
+            6.93147180369123816490e-01, 1.90821492927058770002e-10, 1.0 / 6227020800.0};
+}
+
 template <bool SK = false>
-MHD_HD void sincos_pio2(double x, double& s, double& c)
+MHD_HD void sincos_pio2(double x, double& s, double& c, const MathK* K = nullptr)
 {
     // pi/2 = P1 + P2 + P3 (each the nearest double of the running remainder)
     const double INV_PIO2 = 6.36619772367581382433e-01;
     const double P1 = 1.57079632679489655800e+00;
     const double P2 = 6.12323399573676603587e-17;
     const double P3 = -1.49738490485916983294e-33;
-    const double kf = __builtin_rint(x * INV_PIO2);
-    double r = fma_(-kf, P1, x);
-    r = fma_(-kf, P2, r);
-    r = fma_(-kf, P3, r);
+    const double kf = __builtin_rint(x * (K ? K->inv_pio2 : INV_PIO2));
+    double r = fma_(-kf, K ? K->p1 : P1, x);
+    r = fma_(-kf, K ? K->p2 : P2, r);
+    r = fma_(-kf, K ? K->p3 : P3, r);
     const int q = (int)kf;
     const double z = r * r;
     // sin kernel on [-pi/4, pi/4]
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                  S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double ps = fma_(z, S6, S5);
-    ps = fma_k<SK>(z, ps, S4);
-    ps = fma_k<SK>(z, ps, S3);
-    ps = fma_k<SK>(z, ps, S2);
-    ps = fma_k<SK>(z, ps, S1);
+    double ps = fma_(z, K ? K->s6 : S6, K ? K->s5 : S5);
+    ps = fma_k<SK>(z, ps, K ? K->s4 : S4);
+    ps = fma_k<SK>(z, ps, K ? K->s3 : S3);
+    ps = fma_k<SK>(z, ps, K ? K->s2 : S2);
+    ps = fma_k<SK>(z, ps, K ? K->s1 : S1);
     const double sr = fma_(r * z, ps, r);
     // cos kernel
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double pc = fma_(z, C6, C5);
-    pc = fma_k<SK>(z, pc, C4);
-    pc = fma_k<SK>(z, pc, C3);
-    pc = fma_k<SK>(z, pc, C2);
-    pc = fma_k<SK>(z, pc, C1);
+    double pc = fma_(z, K ? K->c6 : C6, K ? K->c5 : C5);
+    pc = fma_k<SK>(z, pc, K ? K->c4 : C4);
+    pc = fma_k<SK>(z, pc, K ? K->c3 : C3);
+    pc = fma_k<SK>(z, pc, K ? K->c2 : C2);
+    pc = fma_k<SK>(z, pc, K ? K->c1 : C1);
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double cr = w + fma_(z * z, pc, (1.0 - w) - hz);
@@ -98,27 +120,27 @@ MHD_HD void sincos_pio2(double x, double& s, double& c)
 }
 
 template <bool SK = false>
-MHD_HD double exp_neg(double y)
+MHD_HD double exp_neg(double y, const MathK* K = nullptr)
 {
     // exp(-y), 0 <= y <= 700
     const double LOG2E = 1.44269504088896338700e+00;
     const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     const double x = -y;
-    const double nf = __builtin_rint(x * LOG2E);
-    double r = fma_(-nf, LN2_HI, x);
-    r = fma_(-nf, LN2_LO, r);
+    const double nf = __builtin_rint(x * (K ? K->log2e : LOG2E));
+    double r = fma_(-nf, K ? K->ln2_hi : LN2_HI, x);
+    r = fma_(-nf, K ? K->ln2_lo : LN2_LO, r);
     // e^r, |r| <= ln2/2: Taylor to degree 13 (remainder < 5e-18)
-    double p = 1.0 / 6227020800.0;
-    p = fma_k<SK>(p, r, 1.0 / 479001600.0);
-    p = fma_k<SK>(p, r, 1.0 / 39916800.0);
-    p = fma_k<SK>(p, r, 1.0 / 3628800.0);
-    p = fma_k<SK>(p, r, 1.0 / 362880.0);
-    p = fma_k<SK>(p, r, 1.0 / 40320.0);
-    p = fma_k<SK>(p, r, 1.0 / 5040.0);
-    p = fma_k<SK>(p, r, 1.0 / 720.0);
-    p = fma_k<SK>(p, r, 1.0 / 120.0);
-    p = fma_k<SK>(p, r, 1.0 / 24.0);
-    p = fma_k<SK>(p, r, 1.0 / 6.0);
+    double p = K ? K->e13 : 1.0 / 6227020800.0;
+    p = fma_k<SK>(p, r, K ? K->e12 : 1.0 / 479001600.0);
+    p = fma_k<SK>(p, r, K ? K->e11 : 1.0 / 39916800.0);
+    p = fma_k<SK>(p, r, K ? K->e10 : 1.0 / 3628800.0);
+    p = fma_k<SK>(p, r, K ? K->e9 : 1.0 / 362880.0);
+    p = fma_k<SK>(p, r, K ? K->e8 : 1.0 / 40320.0);
+    p = fma_k<SK>(p, r, K ? K->e7 : 1.0 / 5040.0);
+    p = fma_k<SK>(p, r, K ? K->e6 : 1.0 / 720.0);
+    p = fma_k<SK>(p, r, K ? K->e5 : 1.0 / 120.0);
+    p = fma_k<SK>(p, r, K ? K->e4 : 1.0 / 24.0);
+    p = fma_k<SK>(p, r, K ? K->e3 : 1.0 / 6.0);
     p = fma_(p, r, 0.5);
     p = fma_(p, r, 1.0);
     p = fma_(p, r, 1.0);
