@@ -17,8 +17,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # instructions sunk into loops where that avoids a spill, 14 are (320 instead of 1304 bytes of
 # scratch per lane) and the chains run 3-4 % faster.  Results do not depend on either switch
 # (instruction order only; every multiply-add is written out in the sources).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-mllvm", "-disable-machine-licm", "-mllvm", "-sink-insts-to-avoid-spills"]
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+CODEGEN_FLAGS = ["-mllvm", "-disable-machine-licm", "-mllvm", "-sink-insts-to-avoid-spills"]
+FLAGS = BASE_FLAGS + CODEGEN_FLAGS
 
 
 # A test build: every third interpolated root of the deferring period search is replaced by a
@@ -37,7 +38,15 @@ def _compile(out, extra, force, verbose):
     cmd = [HIPCC] + FLAGS + extra + ["-o", out, SRC]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    sys.stderr.write(res.stderr)
+    if res.returncode != 0 and "Unknown command line argument" in res.stderr:
+        # a compiler that does not know the two back-end switches: the same library, slower
+        print("mcmc_amd.build: this hipcc does not know %s; building without (slower kernels)"
+              % " ".join(CODEGEN_FLAGS), file=sys.stderr)
+        res = subprocess.run([HIPCC] + BASE_FLAGS + extra + ["-o", out, SRC])
+    if res.returncode != 0:
+        raise subprocess.CalledProcessError(res.returncode, cmd)
     return out
 
 
