@@ -165,7 +165,10 @@ typedef struct mhd_chains {
                             call.  It is used by calls with 64 <= B <= 4096 chains,
                             candidates = 0 or 2 and sample_prior = 0: the few chains
                             that take longest get four candidates from the start
-                            (as many of the cheapest ones one instead of two), and
+                            (as many of the cheapest ones one instead of two; with
+                            fewer chains than half the GPU's wave slots the slots
+                            left over go to four candidates for the chains at the
+                            head of the order), and
                             a call of at least mhd_sched_min_steps() steps is two
                             launches, the first ending at a deadline, the second
                             giving the chains that are behind more candidates in
