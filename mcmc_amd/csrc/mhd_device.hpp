@@ -56,7 +56,13 @@ struct LayerTable {
 #define MHD_WAVES_PER_SIMD 2
 #endif
 #define MHD_REGS __attribute__((amdgpu_waves_per_eu(MHD_WAVES_PER_SIMD, MHD_WAVES_PER_SIMD)))
+#ifndef MHD_NOINLINE
 #define MHD_NOINLINE __attribute__((noinline))
+#endif
+// the one-abscissa evaluation of the period equation: one out-of-line body
+#ifndef MHD_EVAL_FN
+#define MHD_EVAL_FN __forceinline__
+#endif
 // Polynomial constants kept in registers across the layers of an evaluation (see
 // rayleigh_compound, secular_rayleigh2); 0: set up again in every layer.
 // MHD_PIN_K, one abscissa per lane: 4 all in scalar registers; 1 those of the written-out Horner
@@ -380,7 +386,7 @@ struct SecVal {
 
 // The ONE out-of-line body of the period equation (keeps the kernels within the
 // instruction cache: every search stage calls this instead of inlining a copy).
-__device__ MHD_NOINLINE SecVal eval_secular(int wave, double omega, double c)
+__device__ MHD_EVAL_FN SecVal eval_secular(int wave, double omega, double c)
 {
     SecVal v;
     omega = fmax(omega, 1.0e-4);

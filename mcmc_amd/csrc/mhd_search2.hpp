@@ -1035,6 +1035,9 @@ __device__ __forceinline__ int period_of_abscissa(int i, int kstart, int kend)
     return a;
 }
 
+#ifndef MHD_CURVE_FN
+#define MHD_CURVE_FN MHD_NOINLINE
+#endif
 #ifndef VERIFY_OUT_OF_LINE
 #define VERIFY_OUT_OF_LINE 1
 #endif
@@ -1144,7 +1147,7 @@ __device__ VERIFY_INLINE int verify_pass(int wave, const double* t, double tscal
 // lie closer together than the search's step at short periods, where the sequential search hops
 // between branches and every prediction of it costs a repair.
 // hint: see predict_coarse; use_hint 0: none, 1: for predict_coarse, 2: predict_hint first.
-__device__ MHD_NOINLINE int phase_curve_predicted(int wave, const double* t, int P, double tscale,
+__device__ MHD_CURVE_FN int phase_curve_predicted(int wave, const double* t, int P, double tscale,
                                                   double dc, double* c, EvalCount& cnt,
                                                   int stepwise, const double* hint,
                                                   int use_hint)
