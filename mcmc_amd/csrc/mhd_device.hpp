@@ -78,6 +78,9 @@ struct LayerTable {
 #ifndef MHD_PIN_K2
 #define MHD_PIN_K2 2
 #endif
+#ifndef MHD_PIN_LOVE
+#define MHD_PIN_LOVE 1  // the same in the Love-wave equation (with MHD_PIN_K 4)
+#endif
 
 // Scratch of one wave in dynamic LDS: the layer table of the model it works on, then the state
 // of the predicted search (mhd_search2.hpp).  A kernel that calls the forward model is launched
@@ -360,13 +363,27 @@ __device__ __forceinline__ double secular_love(const LayerTable& T, double omega
     double e1 = T.rho[h] * rb;
     double e2 = T.inv_b[h] * T.inv_b[h];
     int sexp = 0;
+    // (the polynomial constants in scalar registers for all layers, see rayleigh_compound)
+#if MHD_PIN_K == 4
+    MathK KK = math_k();
+    asm volatile("" : "+s"(KK.s1), "+s"(KK.s2), "+s"(KK.s3), "+s"(KK.s4), "+s"(KK.c1), "+s"(KK.c2),
+                      "+s"(KK.c3), "+s"(KK.c4));
+    asm volatile("" : "+s"(KK.e3), "+s"(KK.e4), "+s"(KK.e5), "+s"(KK.e6), "+s"(KK.e7), "+s"(KK.e8),
+                      "+s"(KK.e9), "+s"(KK.e10), "+s"(KK.e11), "+s"(KK.e12));
+    asm volatile("" : "+s"(KK.inv_pio2), "+s"(KK.p1), "+s"(KK.p2), "+s"(KK.p3), "+s"(KK.s5), "+s"(KK.s6),
+                      "+s"(KK.c5), "+s"(KK.c6), "+s"(KK.log2e), "+s"(KK.ln2_hi), "+s"(KK.ln2_lo),
+                      "+s"(KK.e13));
+    const MathK* const K = MHD_PIN_LOVE ? &KK : nullptr;
+#else
+    const MathK* const K = nullptr;
+#endif
 #pragma nounroll
     for (int m = L - 2; m >= 0; --m) {
         const double xmu = T.rho[m] * T.b[m] * T.b[m];
         xkb = omega * T.inv_b[m];
         const double dpth = T.d[m];
         double cosq, y, z, eq, sex;
-        osc_or_evan(k, xkb, dpth, cosq, y, z, eq, sex);
+        osc_or_evan(k, xkb, dpth, cosq, y, z, eq, sex, K);
         const double e10 = mad_(e2 * xmu, z, e1 * cosq);
         const double e20 = mad_(e2, cosq, e1 * y / xmu);
         const double xnor = fmax(fabs(e10), fabs(e20));
