@@ -256,6 +256,8 @@ def main():
     lit, ex = (int(x) for x in chains.n_evals.tolist())
     acc_rate = (chains.counters[:, 0].sum().item() - acc0) / (B * K)
 
+    many_build = chains.steps_lib is not L.lib()
+    wave_slots = torch.cuda.get_device_properties(dev).multi_processor_count * (12 if many_build else 8)
     if rank == 0:
         F = flops_per_eval(nl + 1, args.wave)
         launch_s = kernel_ms * 1e-3 / n_launch
@@ -293,6 +295,8 @@ def main():
                 "steps_per_call": min(args.chunk, K), "calls_timed": n_launch,
                 "search": args.search,
                 "candidates_in_flight": args.candidates, "acceptance_rate": round(acc_rate, 4),
+                "library": "libmcmc_amd_w3.so (three waves per SIMD, for more chains than the "
+                           "GPU holds at two)" if many_build else "libmcmc_amd.so",
                 **({"temperatures": args.temps, "steps_between_sweeps": args.thin,
                     "beta_ladder": args.ladder,
                     "exchanges_accepted_proposed": swap_counts.tolist()}
@@ -308,8 +312,10 @@ def main():
                 # itself: see profiles/ for the counters of this same command
                 "traffic": None,
                 "kernel": "one call of mhd_mh_steps = " + (
-                    "%d x (schedule_kernel, then mh_steps_multi_kernel<4>: workgroups of four "
-                    "waves holding one, two or four chains)"
+                    ("%d x (schedule_kernel, then mh_steps_multi_kernel<4>: workgroups of four "
+                     "waves holding one, two or four chains)" if 2 * B <= wave_slots else
+                     "%d x (schedule_kernel, then mh_steps_multi_kernel<2>: more chains than the "
+                     "GPU holds at once, a queue of one-chain workgroups in the schedule's order)")
                     % (2 if min(args.chunk, K) >= L.lib().mhd_sched_min_steps() else 1)
                     if args.candidates == 2
                     else "mh_steps_multi_kernel<%d>" % args.candidates if args.candidates == 4

@@ -76,6 +76,12 @@ class MhdError(RuntimeError):
 
 
 _lib = None
+_lib_many = None
+# the build of the same library for more chains than the GPU holds at once (three waves per
+# SIMD, at most MANY_MAX_PERIODS data values per curve; mcmc_amd/build.py): used by
+# mcmc_amd.engine for such chain sets when it has been built, MCMC_AMD_MANY=0 turns that off
+MANY_LIB_PATH = os.path.join(_HERE, "lib", "libmcmc_amd_w3.so")
+MANY_MAX_PERIODS = 64
 
 
 def lib():
@@ -87,11 +93,34 @@ def lib():
         raise MhdError(
             f"{LIB_PATH} not found: build the HIP library first (python -m mcmc_amd.build). "
             "There is no CPU fallback.")
+    _lib = _load(LIB_PATH)
+    return _lib
+
+
+def lib_many():
+    """The many-chains build (once), or None when it has not been built, is switched off, or
+    MCMC_AMD_LIB names another library to run."""
+    global _lib_many
+    if _lib_many is None:
+        if (os.environ.get("MCMC_AMD_MANY", "1") == "0" or os.environ.get("MCMC_AMD_LIB")
+                or not os.path.exists(MANY_LIB_PATH)):
+            return None
+        lib()
+        _lib_many = _load(MANY_LIB_PATH)
+    return _lib_many
+
+
+def loaded():
+    """The libraries loaded so far."""
+    return [L for L in (_lib, _lib_many) if L is not None]
+
+
+def _load(path):
     # torch ships its own HIP runtime; it has to be the one already mapped when this library,
     # which is linked against libamdhip64 too, is loaded (the other order leaves the process
     # with two runtimes, and the second one finds no device)
     import torch  # noqa: F401
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     pp, cp = ctypes.POINTER(Problem), ctypes.POINTER(Chains)
     L.mhd_abi_version.restype = ctypes.c_int
     L.mhd_abi_version.argtypes = []
@@ -122,30 +151,37 @@ def lib():
     for name in EXPORTS:
         getattr(L, name)
     if L.mhd_abi_version() != ABI_VERSION:
-        raise MhdError("libmcmc_amd.so ABI version mismatch; rebuild")
-    _lib = L
+        raise MhdError(f"{os.path.basename(path)}: ABI version mismatch; rebuild")
     return L
 
 
-def check(rc):
+def check(rc, L=None):
     if rc != 0:
-        raise MhdError(f"mhd call failed ({rc}): {lib().mhd_last_error().decode()}")
+        raise MhdError(f"mhd call failed ({rc}): {(L or lib()).mhd_last_error().decode()}")
 
 
 def close_decisions():
     """Accept tests settled so far on the current device with u within 16 units in the last place
     of exp(dl) (mhd_close_decisions): the only decisions that numpy's exponential could take the
     other way.  Synchronises with the device."""
-    n = ctypes.c_uint64(0)
-    check(lib().mhd_close_decisions(ctypes.byref(n)))
-    return int(n.value)
+    lib()
+    total = 0
+    for L in loaded():
+        n = ctypes.c_uint64(0)
+        check(L.mhd_close_decisions(ctypes.byref(n)), L)
+        total += int(n.value)
+    return total
 
 
 def check_waits():
     """Raises if a wait between the waves of a workgroup has ever timed out on the current device
     (mhd_wait_timeouts): the results since then are not valid.  Synchronises with the device."""
-    n = ctypes.c_uint64(0)
-    check(lib().mhd_wait_timeouts(ctypes.byref(n)))
-    if n.value:
-        raise MhdError(f"{n.value} wait(s) between the waves of a chain timed out on the device: "
+    lib()
+    total = 0
+    for L in loaded():
+        n = ctypes.c_uint64(0)
+        check(L.mhd_wait_timeouts(ctypes.byref(n)), L)
+        total += int(n.value)
+    if total:
+        raise MhdError(f"{total} wait(s) between the waves of a chain timed out on the device: "
                        "the chains computed since are not valid")

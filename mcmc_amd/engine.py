@@ -215,6 +215,13 @@ class DeviceChains:
                 and self.beta.is_contiguous() and self.beta.device == self.m.device
         self.n_evals = torch.zeros(2, dtype=torch.int64, device=dev)
         self.sched = torch.zeros(int(L.lib().mhd_sched_bytes(B)), dtype=torch.uint8, device=dev)
+        # More chains than the GPU holds at two waves per SIMD (two candidates each): their
+        # steps go through the many-chains build of the library when there is one and the
+        # problem fits it (same ABI, same bits; mcmc_amd/build.py).
+        self.steps_lib = L.lib()
+        slots = 8 * torch.cuda.get_device_properties(dev).multi_processor_count
+        if 2 * B > slots and prob.ND <= L.MANY_MAX_PERIODS and L.lib_many() is not None:
+            self.steps_lib = L.lib_many()
         if os.environ.get("MCMC_AMD_NO_SCHED"):  # (A/B measurements: calls without the schedule)
             self.sched = None
 
@@ -283,12 +290,15 @@ class DeviceChains:
                 diag.hist_cov = out["hist_cov"].data_ptr()
         ch = self.struct()
         with torch.cuda.device(dev):
-            entry = L.lib().mhd_mh_steps_static if static_scratch else L.lib().mhd_mh_steps
+            # (the static scratch is the default build's: mhd_init() was called on that one)
+            lib = L.lib() if static_scratch else self.steps_lib
+            entry = lib.mhd_mh_steps_static if static_scratch else lib.mhd_mh_steps
             L.check(entry(
                 self.prob.cref(self.n_layers_b), ctypes.byref(ch), B, S, _ptr(idx), _ptr(cauchy),
                 _ptr(u_acc), float(T), int(rotate), int(bool(sample_prior)), _ptr(acc),
                 _ptr(st), int(hist_every), _ptr(hm), _ptr(hl), _ptr(hp),
-                None if diag is None else ctypes.byref(diag), _ptr(self.n_evals), _stream(dev)))
+                None if diag is None else ctypes.byref(diag), _ptr(self.n_evals), _stream(dev)),
+                lib)
         return out
 
     def stepsize_tuning(self):

@@ -84,3 +84,54 @@ def test_chains_every_way_of_running_agrees_at_full_size():
     assert (cnt[:, 0] + cnt[:, 1] == S).all()            # every step accepted or rejected
     assert (cnt[:, 2] + cnt[:, 4] <= cnt[:, 1]).all()    # invalid proposals are rejections
     assert 0.1 < cnt[:, 0].sum() / (B * S) < 0.6
+
+
+def test_more_chains_than_the_gpu_holds_go_through_the_many_chains_build():
+    """With more chains than the GPU holds at two waves per SIMD the engine sends the steps
+    through the build of the library with three waves per SIMD (mcmc_amd/build.py): the same
+    chains bit for bit as the default build gives, both where that build still holds all chains
+    at once (1280) and where its launches are a queue (1792)."""
+    import torch
+    from mcmc_amd import _lib as L
+    from mcmc_amd.engine import DeviceChains, DeviceProblem
+    assert L.lib_many() is not None, "build first: python -m mcmc_amd.build"
+    rng = np.random.default_rng(2024)
+    periods = np.flip(1 / np.logspace(0.3, 1.3, P)).copy()
+    bounds = np.array([[0.001, 0.15, 0.149]] * NL + [[0.1, 2.0, 1.9]] * (NL + 1))
+    prob0 = DeviceProblem(NL, 1.75, periods)
+    for Bm, S in ((1280, 60), (1792, 30)):
+        starts = np.empty((0, 2 * NL + 1))
+        while starts.shape[0] < Bm:
+            cand = rng.uniform(bounds[:, 0], bounds[:, 1], size=(2 * Bm, 2 * NL + 1))
+            order = np.argsort(cand[:, :NL], axis=1, kind="stable")
+            cand[:, :NL] = np.take_along_axis(cand[:, :NL], order, axis=1)
+            cand[:, NL:2 * NL] = np.take_along_axis(cand[:, NL:2 * NL], order, axis=1)
+            _, st = prob0.forward(torch.tensor(cand, device=prob0.device))
+            starts = np.concatenate([starts, cand[st.cpu().numpy() == 0]])
+        starts = starts[:Bm]
+        obs = prob0.forward(torch.tensor(starts[:1], device=prob0.device))[0][0].cpu().numpy() \
+            + 0.025 * rng.standard_normal(P)
+        prob = DeviceProblem(NL, 1.75, periods, obs, "normal", {"std": 0.025}, bounds)
+        dev, NP = prob.device, 2 * NL + 1
+        idx = torch.tensor(rng.integers(0, NP, (S, Bm)).astype(np.int32), device=dev)
+        cauchy = torch.tensor(np.tan(np.pi * (rng.uniform(size=(S, Bm)) - 0.5)), device=dev)
+        u_acc = torch.tensor(rng.uniform(size=(S, Bm)), device=dev)
+        res = []
+        for many in (True, False):
+            ch = DeviceChains(prob, starts, 0.05)
+            assert ch.steps_lib is L.lib_many()
+            if not many:
+                ch.steps_lib = L.lib()
+            assert int((ch.init_likelihood() != 0).sum()) == 0
+            out1 = ch.steps(idx[:S // 2], cauchy[:S // 2], u_acc[:S // 2], hist_every=10)
+            out2 = ch.steps(idx[S // 2:], cauchy[S // 2:], u_acc[S // 2:], hist_every=5)
+            torch.cuda.synchronize()
+            res.append((ch.m.clone(), ch.logL.clone(), ch.pred.clone(), ch.counters.clone(),
+                        torch.cat([out1["accepted"], out2["accepted"]]),
+                        torch.cat([out1["status"], out2["status"]]),
+                        out1["hist_m"], out2["hist_logL"], int(ch.n_evals[0])))
+        for x, y in zip(res[0][:-1], res[1][:-1]):
+            assert torch.equal(x, y)
+        assert res[0][-1] == res[1][-1] > 0
+        assert int(res[0][3][:, 0].sum()) > 0
+    L.check_waits()

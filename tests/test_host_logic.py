@@ -15,14 +15,17 @@ def test_library_exports_every_declared_symbol():
     """libmcmc_amd.so loads without a GPU and exports what include/mcmc_amd.h declares."""
     from mcmc_amd import _lib as L
     assert os.path.exists(L.LIB_PATH), "build first: python -m mcmc_amd.build"
-    lib = ctypes.CDLL(L.LIB_PATH)
+    assert os.path.exists(L.MANY_LIB_PATH), "build first: python -m mcmc_amd.build"
     header = open(os.path.join(ROOT, "include", "mcmc_amd.h")).read()
     declared = set(re.findall(r"\b(mhd_[a-z_]+)\s*\(", header))
     assert declared == set(L.EXPORTS)
-    for name in declared:
-        assert hasattr(lib, name), name
-    lib.mhd_abi_version.restype = ctypes.c_int
-    assert lib.mhd_abi_version() == L.ABI_VERSION
+    # (the build for many chains per GPU has the same ABI)
+    for path in (L.LIB_PATH, L.MANY_LIB_PATH):
+        lib = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(lib, name), (path, name)
+        lib.mhd_abi_version.restype = ctypes.c_int
+        assert lib.mhd_abi_version() == L.ABI_VERSION
     # struct layouts agree with the header's field order and sizes
     assert ctypes.sizeof(L.Problem) == 8 * 4 + 3 * 8 + 6 * 8 + 2 * 4
     assert ctypes.sizeof(L.Chains) == 12 * 8
